@@ -1,0 +1,115 @@
+/* pnmol_hip.h -- C ABI of the MI355X-native PNMOL white-noise EK1 filter step.
+ *
+ * The reference (schmidtjonathan/pnmol-experiments) is pure Python/JAX and has no
+ * FFI of its own; its boundary for this path is the Python class
+ * contract `pnmol.white.LinearWhiteNoiseEK1.{initialize,attempt_step,solve}`.  This header
+ * is the C boundary a binding for that contract binds to; every entry point names the
+ * reference code it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - return 0 = ok, <0 = error: -1 bad argument, -2 HIP error, -3 innovation matrix not
+ *     positive definite (see `pnmol_last_error`), -4 out of memory.
+ *   - caller owns every host buffer; the library owns all device memory behind the
+ *     opaque handles.  Matrices are row-major.
+ *   - state vectors / covariances crossing this boundary use the reference's
+ *     F-flattened order (`mean.reshape(-1, order="F")`, white.py:104): index j*n + i is
+ *     derivative i at mesh point j.  `mean_nd` buffers are (n, d) row-major like
+ *     `state.y.mean`.  Everything is in the NON-preconditioned ("raw") coordinates the
+ *     reference's `PDEFilterState` carries.
+ *   - one ctx <-> one device <-> one HIP stream.  A ctx is not thread-safe; different
+ *     ctxs are independent (one thread or process per GPU).
+ *   - dtype: fp64 (the reference runs with jax_enable_x64, src/pnmol/__init__.py:9-11).
+ */
+#ifndef PNMOL_HIP_H
+#define PNMOL_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pnmol_ctx pnmol_ctx;
+typedef struct pnmol_filter pnmol_filter; /* model + workspace: L, B, E, R, Gamma, nu       */
+typedef struct pnmol_state pnmol_state;   /* device-resident (mean, covariance, t)          */
+
+/* library / device ----------------------------------------------------------------- */
+int pnmol_abi_version(void);
+int pnmol_device_count(int* count);
+int pnmol_ctx_create(int device, pnmol_ctx** out);
+int pnmol_ctx_destroy(pnmol_ctx* ctx);
+int pnmol_ctx_synchronize(pnmol_ctx* ctx);
+const char* pnmol_last_error(pnmol_ctx* ctx);
+
+/* problem description = the attributes `attempt_step` reads from `pde`
+ * (white.py:96-146, :169-186; pde/mixins.py:19-59) and from the solver
+ * (`num_derivatives`, pdefilter.py:37-70; Gamma = chol(spatial_kernel(X, X.T)),
+ * white.py:82-94). */
+typedef struct pnmol_filter_desc {
+    int d;                 /* mesh points = pde.L.shape[0]                            */
+    int num_derivatives;   /* nu; n = nu + 1 in {2,3,4}                               */
+    int nB;                /* rows of pde.B                                           */
+    const double* L;       /* (d,d)  pde.L                                            */
+    const double* B;       /* (nB,d) pde.B                                            */
+    const double* E_sqrtm; /* (d,d)  pde.E_sqrtm                                      */
+    const double* R_sqrtm; /* (nB,nB) pde.R_sqrtm                                     */
+    const double* Gamma;   /* (d,d) lower; iwp.wp_diffusion_sqrtm (base/iwp.py:10)    */
+} pnmol_filter_desc;
+
+int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_filter** out);
+int pnmol_filter_destroy(pnmol_filter* f);
+
+/* Step-invariant part of `estimate_error` (white.py:153-162) for step size dt:
+ * Sq = H (Ql Ql^T) H^T + E E^T depends only on dt for a linear PDE.  The caller passes
+ * Sq^-1 (m,m) and diag(Sq) (m), m = d + nB; the per-step part z^T Sq^-1 z runs on device.
+ * Without it, the error estimate of a step with this dt is reported as NaN. */
+int pnmol_filter_set_error_model(pnmol_filter* f, double dt, const double* Sq_inv,
+                                 const double* Sq_diag);
+
+/* states ----------------------------------------------------------------------------- */
+int pnmol_state_create(pnmol_filter* f, pnmol_state** out);
+int pnmol_state_destroy(pnmol_state* s);
+int pnmol_state_clone(const pnmol_state* s, pnmol_state** out); /* reject/retry, pdefilter.py:192-223 */
+/* upload `PDEFilterState(t, y=(mean, cov))`; cov = cov_sqrtm @ cov_sqrtm.T (base/rv.py:12-14) */
+int pnmol_state_set(pnmol_state* s, double t, const double* mean_nd, const double* cov_DD);
+int pnmol_state_get_time(const pnmol_state* s, double* t);
+int pnmol_state_get_mean(const pnmol_state* s, double* mean_nd);       /* (n,d)            */
+int pnmol_state_get_cov(const pnmol_state* s, double* cov_DD);         /* (D,D) F-order    */
+/* diag(cov) as (n,d): what experiments/figure1.py:76-80 reads out (`stds**2`)            */
+int pnmol_state_get_marginal_var(const pnmol_state* s, double* var_nd);
+
+/* one step ----------------------------------------------------------------------------- */
+typedef struct pnmol_step_out {
+    double t_new;                   /* state.t + dt                                       */
+    double diffusion_squared_local; /* white.py:125-128 formula with the Cholesky factor
+                                       of S (positive diagonal): |Ls^-T z|^2 / m          */
+    double sigma2_whitened;         /* z^T S^-1 z / m (the quasi-MLE the comment intends) */
+    double error_sigma2;            /* z^T Sq^-1 z / m of estimate_error (NaN if no model)*/
+    int info;                       /* -1 ok, else index of first non-positive pivot      */
+} pnmol_step_out;
+
+/* `_WhiteNoiseEK1Base.attempt_step` with `LinearWhiteNoiseEK1.evaluate_ode`
+ * (white.py:96-146, :169-186).  `in` is not modified; `out` may not alias `in`.
+ * `error_estimate_d` (d) optional: dt * sqrt(diag Sq) * sigma (white.py:117-129). */
+int pnmol_filter_step(pnmol_filter* f, const pnmol_state* in, double dt, pnmol_state* out,
+                      pnmol_step_out* info, double* error_estimate_d);
+
+/* k steps of constant dt with no host synchronisation in between -- the loop body of
+ * `PDEFilter.solution_generator` under `step.Constant` (pdefilter.py:140-160,
+ * odetools/step.py:30-55).  `s` is advanced in place.  Optional outputs, each written
+ * once after the last step: means_kd / stds_kd (k,d) = `sol.mean[1:, 0]` and
+ * sqrt(diag(cov) E0^T) per step (figure1.py:76-80, uncalibrated); info_k (k entries). */
+int pnmol_filter_steps(pnmol_filter* f, pnmol_state* s, int k, double dt, double* means_kd,
+                       double* stds_kd, pnmol_step_out* info_k);
+
+/* timing hooks for bench.py: HIP events on the ctx stream around the last `steps` call */
+int pnmol_filter_last_steps_ms(pnmol_filter* f, float* ms);
+
+/* debugging / tests: copy an internal device buffer to the host.
+ * which: 0 = predicted covariance (Dp*Dp, derivative-major padded), 1 = G work matrix,
+ * 2 = F factor matrix [Ls; W; r^T], 3 = predicted mean (Dp), 4 = z (mp).  `count` doubles. */
+int pnmol_filter_debug_read(pnmol_filter* f, int which, double* dst, long count);
+int pnmol_filter_dims(const pnmol_filter* f, int* d, int* n, int* m, int* dp, int* mp);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PNMOL_HIP_H */

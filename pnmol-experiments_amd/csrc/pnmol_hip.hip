@@ -1,0 +1,1122 @@
+// pnmol_hip.hip -- MI355X (gfx950) implementation of the PNMOL white-noise EK1 step.
+//
+// Reference path (schmidtjonathan/pnmol-experiments): src/pnmol/white.py:96-146
+// (attempt_step), :169-186 (evaluate_ode), base/iwp.py:13-97 (Phi/Q, preconditioner),
+// base/sqrt.py:8-95 (QR predict/update).  The reference is a square-root (QR) filter; its own
+// tests (tests/test_base/test_sqrt.py:48-78) assert equivalence with the classic form
+//     P- = A P A^T + Q,  S = H P- H^T + R,  S = Ls Ls^T,  W = P- H^T Ls^-T,  P = P- - W W^T,
+// which is what runs here, in the reference's Nordsieck-preconditioned coordinates
+// (white.py:97-104) so that all entries are O(1).
+//
+// Device layout (all fp64, row-major, zero padded):
+//   state index  (a, j) -> a*dp + j      a = derivative 0..n-1, j = mesh point   ("derivative-major";
+//                the C ABI converts from/to the reference's point-major j*n + a)
+//   P, P-        Dp x Dp, Dp = n*dp, dp = d rounded up to 32
+//   G, F         (mp + Dp + 32) x mp "tall" matrices, mp = (d + nB) rounded up to 32:
+//                G = [ S ; P- H^T ; z^T ]  is factorised column-block by column-block
+//                (right-looking, NB = 32) into  F = [ Ls ; W ; r^T ],  r = Ls^-1 z.
+//   H            never materialised: H = c1 [I;0] (x) e1^T + c0 Hv (x) e0^T with Hv = [-L; B] in ELL
+//                (stencil rows), c_i = Nordsieck scale of derivative i  (white.py:110-115, :171-186).
+//   A, Q         never materialised: A = A1 (x) I_d, Q = Q1 (x) K with K = Gamma Gamma^T
+//                (base/iwp.py:32-53) -> n x n block transform per (j,k) pair.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pnmol_hip.h"
+
+namespace {
+
+constexpr int NB = 32;        // factorisation block
+constexpr int TLD = NB + 1;   // LDS leading dimension of a 32x32 tile (bank-conflict pad)
+constexpr int MAXN = 4;       // max derivatives + 1
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+struct IwpConsts {
+    double A1[MAXN * MAXN];  // flip(pascal_lower)  base/iwp.py:24-27
+    double Q1[MAXN * MAXN];  // flip(hilbert)       base/iwp.py:29
+    double ts[MAXN];         // frame change  s_old[a] / s_new[a]
+};
+
+// ------------------------------------------------------------------------------------------
+// predict:  P-_ab = sum_ce A1[a,c] A1[b,e] ts_c ts_e P_ce + Q1[a,b] K      (HBM-bound pass)
+// ------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(256) void k_predict(const double* __restrict__ Pin, double* __restrict__ Pout,
+                                                 const double* __restrict__ Kg, IwpConsts c, int dp) {
+    const int k = blockIdx.x * 32 + threadIdx.x;
+    const int j = blockIdx.y * 8 + threadIdx.y;
+    const long Dp = (long)N * dp;
+    double X[N][N];
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+#pragma unroll
+        for (int b = 0; b < N; ++b) X[a][b] = c.ts[a] * c.ts[b] * Pin[((long)a * dp + j) * Dp + (long)b * dp + k];
+    const double kjk = Kg[(long)j * dp + k];
+    double T[N][N];
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            double s = 0.0;
+#pragma unroll
+            for (int q = 0; q < N; ++q) s += c.A1[a * MAXN + q] * X[q][e];
+            T[a][e] = s;
+        }
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+#pragma unroll
+        for (int b = 0; b < N; ++b) {
+            double s = c.Q1[a * MAXN + b] * kjk;
+#pragma unroll
+            for (int e = 0; e < N; ++e) s += T[a][e] * c.A1[b * MAXN + e];
+            Pout[((long)a * dp + j) * Dp + (long)b * dp + k] = s;
+        }
+}
+
+template <int N>
+__global__ void k_predict_mean(const double* __restrict__ min, double* __restrict__ mout, IwpConsts c, int dp) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= dp) return;
+    double x[N];
+#pragma unroll
+    for (int a = 0; a < N; ++a) x[a] = c.ts[a] * min[a * dp + j];
+#pragma unroll
+    for (int a = 0; a < N; ++a) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < N; ++q) s += c.A1[a * MAXN + q] * x[q];
+        mout[a * dp + j] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// H apply (stencil gather).  ELL arrays are [e*mp + i].
+// ------------------------------------------------------------------------------------------
+struct MeasModel {
+    const int* ell_col;
+    const double* ell_val;
+    int w, d, m, dp, mp;
+    double c0, c1;
+};
+
+// G[mp + row, i] = (P- H^T)[row, i]
+__global__ __launch_bounds__(256) void k_pht(const double* __restrict__ Ppred, double* __restrict__ G, MeasModel mm,
+                                             long Dp) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const long row = blockIdx.y;
+    if (i >= mm.mp) return;
+    const double* prow = Ppred + row * Dp;
+    double v = 0.0;
+    if (i < mm.m) {
+        if (i < mm.d) v = mm.c1 * prow[mm.dp + i];
+        for (int e = 0; e < mm.w; ++e) {
+            const int cidx = mm.ell_col[e * mm.mp + i];
+            if (cidx >= 0) v += mm.c0 * mm.ell_val[e * mm.mp + i] * prow[cidx];
+        }
+    }
+    G[((long)mm.mp + row) * mm.mp + i] = v;
+}
+
+// z = H m- + shift, into the extra row block of G and into zbuf
+__global__ void k_zrow(const double* __restrict__ mpred, const double* __restrict__ shift, double* __restrict__ G,
+                       double* __restrict__ zbuf, MeasModel mm, long Dp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= mm.mp) return;
+    double v = 0.0;
+    if (i < mm.m) {
+        if (i < mm.d) v = mm.c1 * mpred[mm.dp + i];
+        for (int e = 0; e < mm.w; ++e) {
+            const int cidx = mm.ell_col[e * mm.mp + i];
+            if (cidx >= 0) v += mm.c0 * mm.ell_val[e * mm.mp + i] * mpred[cidx];
+        }
+        v += shift[i];
+    }
+    G[((long)mm.mp + Dp) * mm.mp + i] = v;
+    zbuf[i] = v;
+}
+
+// G[ip, i] = S[ip, i] = (H (P- H^T))[ip, i] + R[ip, i];  identity on the padding
+__global__ __launch_bounds__(256) void k_sbuild(double* __restrict__ G, const double* __restrict__ rdiag,
+                                                const double* __restrict__ Rdense, MeasModel mm) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int ip = blockIdx.y;
+    if (i >= mm.mp) return;
+    double v;
+    if (ip < mm.m && i < mm.m) {
+        v = 0.0;
+        if (ip < mm.d) v = mm.c1 * G[((long)mm.mp + mm.dp + ip) * mm.mp + i];
+        for (int e = 0; e < mm.w; ++e) {
+            const int cidx = mm.ell_col[e * mm.mp + ip];
+            if (cidx >= 0) v += mm.c0 * mm.ell_val[e * mm.mp + ip] * G[((long)mm.mp + cidx) * mm.mp + i];
+        }
+        if (ip == i) v += rdiag[i];
+        if (Rdense) v += Rdense[(long)ip * mm.mp + i];
+    } else {
+        v = (ip == i) ? 1.0 : 0.0;
+    }
+    G[(long)ip * mm.mp + i] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// 32x32 Cholesky + triangular inverse of an LDS tile by one 256-thread workgroup.
+// In: T symmetric (lower read).  Out: T = L (upper zeroed), X = L^-1 (lower).
+// ------------------------------------------------------------------------------------------
+__device__ void potrf32_inv(double* T, double* X, double* rs, int tid, int* info, int base) {
+    const int i = tid >> 3, kq = tid & 7;
+    for (int j = 0; j < NB; ++j) {
+        __syncthreads();
+        const double p = T[j * TLD + j];
+        if (i > j) {
+            const double f = T[i * TLD + j] / p;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = kq + 8 * q;
+                if (k > j && k <= i) T[i * TLD + k] -= f * T[k * TLD + j];
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < NB) {
+        const double p = T[tid * TLD + tid];
+        if (!(p > 0.0)) atomicMin(info, base + tid);
+        rs[tid] = 1.0 / sqrt(p);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = kq + 8 * q;
+        T[i * TLD + k] = (k <= i) ? T[i * TLD + k] * rs[k] : 0.0;
+        X[i * TLD + k] = 0.0;
+    }
+    __syncthreads();
+    const int c = tid >> 3;  // column of X owned by this 8-lane group
+    for (int r = 0; r < NB; ++r) {
+        double part = 0.0;
+        if (r >= c)
+            for (int k = c + kq; k < r; k += 8) part += T[r * TLD + k] * X[k * TLD + c];
+        part += __shfl_xor(part, 1);
+        part += __shfl_xor(part, 2);
+        part += __shfl_xor(part, 4);
+        if (kq == 0 && r >= c) X[r * TLD + c] = ((r == c ? 1.0 : 0.0) - part) * rs[r];
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void tile_g2s(const double* __restrict__ g, long ld, double* s, int tid) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + 256 * q, r = e >> 5, cc = e & 31;
+        s[r * TLD + cc] = g[(long)r * ld + cc];
+    }
+}
+
+// first diagonal block: F[0,0] = chol(G[0,0]), Linv[0] = its inverse
+__global__ __launch_bounds__(256) void k_diag0(const double* __restrict__ G, double* __restrict__ F,
+                                               double* __restrict__ Linv, int ld, int* info) {
+    __shared__ double sT[NB * TLD], sX[NB * TLD], rs[NB];
+    const int tid = threadIdx.x;
+    tile_g2s(G, ld, sT, tid);
+    potrf32_inv(sT, sX, rs, tid, info, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + 256 * q, r = e >> 5, cc = e & 31;
+        F[(long)r * ld + cc] = sT[r * TLD + cc];
+        Linv[r * NB + cc] = sX[r * TLD + cc];
+    }
+}
+
+// panel j:  L_Ij = G_Ij Linv_j^T  for all row blocks I > j  (written to F by the c == 0 column),
+//           G_IK -= L_Ij L_Kj^T   for trailing column blocks K = j+1+c,
+//           and the workgroup owning (j+1, j+1) factorises it for the next panel.
+__global__ __launch_bounds__(256) void k_panel(double* __restrict__ G, double* __restrict__ F,
+                                               double* __restrict__ Linv, int ld, int j, int CB, int RBS,
+                                               int* info) {
+    __shared__ double sA[NB * TLD], sB[NB * TLD], sI[NB * TLD], rs[NB];
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+    const int I = j + 1 + blockIdx.x;
+    const int c = blockIdx.y;
+    const int Kc = j + 1 + c;
+    const bool trailing = Kc < CB;
+    if (trailing && I < RBS && I < Kc) return;  // strictly-upper tile of the symmetric part
+
+    tile_g2s(Linv + (long)j * NB * NB, NB, sI, tid);
+    tile_g2s(G + (long)I * NB * ld + (long)j * NB, ld, sA, tid);
+    if (trailing) tile_g2s(G + (long)Kc * NB * ld + (long)j * NB, ld, sB, tid);
+    __syncthreads();
+
+    const int wr = w >> 1, wc = w & 1;
+    const int fr = l & 15, fk = l >> 4;
+    d4 li = {0, 0, 0, 0}, lk = {0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < NB / 4; ++s) {
+        const double b = sI[(wc * 16 + fr) * TLD + 4 * s + fk];
+        li = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[(wr * 16 + fr) * TLD + 4 * s + fk], b, li, 0, 0, 0);
+        if (trailing) lk = __builtin_amdgcn_mfma_f64_16x16x4f64(sB[(wr * 16 + fr) * TLD + 4 * s + fk], b, lk, 0, 0, 0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = wr * 16 + fk + 4 * r, col = wc * 16 + fr;
+        sA[row * TLD + col] = li[r];
+        if (trailing) sB[row * TLD + col] = lk[r];
+        if (c == 0) F[((long)I * NB + row) * ld + (long)j * NB + col] = li[r];
+    }
+    if (!trailing) return;
+    __syncthreads();
+
+    double* gt = G + (long)I * NB * ld + (long)Kc * NB;
+    d4 acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = gt[(long)(wr * 16 + fk + 4 * r) * ld + wc * 16 + fr];
+#pragma unroll
+    for (int s = 0; s < NB / 4; ++s)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-sA[(wr * 16 + fr) * TLD + 4 * s + fk],
+                                                   sB[(wc * 16 + fr) * TLD + 4 * s + fk], acc, 0, 0, 0);
+    if (!(blockIdx.x == 0 && c == 0)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gt[(long)(wr * 16 + fk + 4 * r) * ld + wc * 16 + fr] = acc[r];
+        return;
+    }
+    // next diagonal block (j+1, j+1)
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sA[(wr * 16 + fk + 4 * r) * TLD + wc * 16 + fr] = acc[r];
+    potrf32_inv(sA, sB, rs, tid, info, (j + 1) * NB);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + 256 * q, r = e >> 5, cc = e & 31;
+        F[((long)(j + 1) * NB + r) * ld + (long)(j + 1) * NB + cc] = sA[r * TLD + cc];
+        Linv[(long)(j + 1) * NB * NB + r * NB + cc] = sB[r * TLD + cc];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// covariance down-date  P = P- - W W^T  on 16x16 point tiles x all n*n derivative blocks.
+// One workgroup (4 waves) per lower tile pair (J >= K); the waves split the inner (measurement)
+// dimension in 16-column chunks, partial sums are combined through LDS, wave 0 writes the tile
+// and its mirror image.  W = F + mp*ld  (Dp x mp).
+// ------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(256) void k_downdate(const double* __restrict__ Ppred, const double* __restrict__ W,
+                                                  double* __restrict__ Pout, double* __restrict__ var,
+                                                  int dp, int mp) {
+    constexpr int SLD = 17;                      // staging leading dim (16 cols + pad)
+    constexpr int STG = 2 * N * 16 * SLD;        // doubles per wave staging
+    constexpr int RED = N * N * 4 * 64;          // doubles per wave of partial sums
+    constexpr int LDS_D = (4 * STG > 3 * RED) ? 4 * STG : 3 * RED;
+    __shared__ double smem[LDS_D];
+    const int J = blockIdx.y, K = blockIdx.x;
+    if (K > J) return;
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+    const long Dp = (long)N * dp;
+    double* st = smem + w * STG;
+    const int fr = l & 15, fk = l >> 4;
+    const int lr = l >> 3, lc = (l & 7) * 2;  // staging load: 8 rows x 16 cols per instruction
+
+    d4 acc[N][N];
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+#pragma unroll
+        for (int b = 0; b < N; ++b) acc[a][b] = (d4){0, 0, 0, 0};
+
+    const int nchunks = mp / 16;
+    const int niter = (nchunks + 3) / 4;
+    for (int it = 0; it < niter; ++it) {
+        const int chunk = it * 4 + w;
+        __syncthreads();
+        if (chunk < nchunks) {
+            const int i0 = chunk * 16;
+#pragma unroll
+            for (int a = 0; a < N; ++a)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int r = lr + 8 * h;
+                    const double2 va = *reinterpret_cast<const double2*>(W + ((long)a * dp + J * 16 + r) * mp + i0 + lc);
+                    const double2 vb = *reinterpret_cast<const double2*>(W + ((long)a * dp + K * 16 + r) * mp + i0 + lc);
+                    st[(a * 16 + r) * SLD + lc] = va.x;
+                    st[(a * 16 + r) * SLD + lc + 1] = va.y;
+                    st[((N + a) * 16 + r) * SLD + lc] = vb.x;
+                    st[((N + a) * 16 + r) * SLD + lc + 1] = vb.y;
+                }
+        }
+        __syncthreads();
+        if (chunk < nchunks) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                double fa[N], fb[N];
+#pragma unroll
+                for (int a = 0; a < N; ++a) {
+                    fa[a] = st[(a * 16 + fr) * SLD + kk * 4 + fk];
+                    fb[a] = st[((N + a) * 16 + fr) * SLD + kk * 4 + fk];
+                }
+#pragma unroll
+                for (int a = 0; a < N; ++a)
+#pragma unroll
+                    for (int b = 0; b < N; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+    if (w > 0) {
+        double* rd = smem + (w - 1) * RED;
+#pragma unroll
+        for (int a = 0; a < N; ++a)
+#pragma unroll
+            for (int b = 0; b < N; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rd[((a * N + b) * 4 + r) * 64 + l] = acc[a][b][r];
+    }
+    __syncthreads();
+    if (w != 0) return;
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+#pragma unroll
+        for (int b = 0; b < N; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double s = acc[a][b][r];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) s += smem[q * RED + ((a * N + b) * 4 + r) * 64 + l];
+                const int row = fk + 4 * r, col = fr;
+                const long gi = ((long)a * dp + J * 16 + row) * Dp + (long)b * dp + K * 16 + col;
+                const double x = Ppred[gi] - s;
+                Pout[gi] = x;
+                if (J != K) Pout[((long)b * dp + K * 16 + col) * Dp + (long)a * dp + J * 16 + row] = x;
+                if (J == K && a == b && row == col) var[a * dp + J * 16 + row] = x;
+            }
+}
+
+// mean update  m = m- - W r   (one wave per state row)
+__global__ __launch_bounds__(256) void k_meanupd(const double* __restrict__ mpred, const double* __restrict__ W,
+                                                 const double* __restrict__ r, double* __restrict__ mout, int mp,
+                                                 long Dp) {
+    const int l = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= Dp) return;
+    double s = 0.0;
+    for (int i = l; i < mp; i += 64) s += W[row * mp + i] * r[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (l == 0) mout[row] = mpred[row] - s;
+}
+
+__device__ double block_sum(double v, double* sred) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) sred[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int q = 0; q < (int)(blockDim.x >> 6); ++q) t += sred[q];
+    return t;
+}
+
+// rec[0] = |r|^2,  rec[2] = z^T Sqinv z   (single workgroup of 1024 threads)
+__global__ __launch_bounds__(1024) void k_stats(const double* __restrict__ r, const double* __restrict__ z,
+                                                const double* __restrict__ Sqinv, double* __restrict__ rec, int mp) {
+    __shared__ double sred[16];
+    double a = 0.0, e = 0.0;
+    for (int col = threadIdx.x; col < mp; col += blockDim.x) {
+        a += r[col] * r[col];
+        if (Sqinv) {
+            double y = 0.0;
+            for (int i = 0; i < mp; ++i) y += Sqinv[(long)i * mp + col] * z[i];
+            e += y * z[col];
+        }
+    }
+    a = block_sum(a, sred);
+    e = block_sum(e, sred);
+    if (threadIdx.x == 0) {
+        rec[0] = a;
+        rec[2] = Sqinv ? e : nan("");
+    }
+}
+
+// x = Ls^-T z by block back-substitution with the inverted diagonal blocks;  rec[1] = |x|^2.
+// This is the reference's `solve_triangular(Sl.T, z)` (white.py:125) with the Cholesky factor.
+__global__ __launch_bounds__(256) void k_backsolve(const double* __restrict__ F, const double* __restrict__ Linv,
+                                                   const double* __restrict__ z, double* __restrict__ rec, int mp,
+                                                   int CB, double* __restrict__ xout) {
+    extern __shared__ double sx[];  // mp + 256 + 32
+    double* part = sx + mp;
+    double* tt = part + 256;
+    __shared__ double sred[4];
+    const int tid = threadIdx.x, c = tid & 31, g = tid >> 5;
+    for (int i = tid; i < mp; i += 256) sx[i] = z[i];
+    __syncthreads();
+    for (int jb = CB - 1; jb >= 0; --jb) {
+        double s = 0.0;
+        for (int row = (jb + 1) * NB + g; row < mp; row += 8) s += F[(long)row * mp + jb * NB + c] * sx[row];
+        part[g * 32 + c] = s;
+        __syncthreads();
+        if (tid < 32) {
+            double t = sx[jb * NB + tid];
+            for (int q = 0; q < 8; ++q) t -= part[q * 32 + tid];
+            tt[tid] = t;
+        }
+        __syncthreads();
+        if (tid < 32) {
+            double xv = 0.0;
+            for (int q = tid; q < 32; ++q) xv += Linv[(long)jb * NB * NB + q * NB + tid] * tt[q];
+            sx[jb * NB + tid] = xv;
+        }
+        __syncthreads();
+    }
+    double a = 0.0;
+    for (int i = tid; i < mp; i += 256) {
+        a += sx[i] * sx[i];
+        if (xout) xout[i] = sx[i];
+    }
+    a = block_sum(a, sred);
+    if (tid == 0) rec[1] = a;
+}
+
+// per-step read-out of the parity quantities (experiments/figure1.py:76-80), raw coordinates
+__global__ void k_readout(const double* __restrict__ mean, const double* __restrict__ var, double* __restrict__ means,
+                          double* __restrict__ stds, double s0, int d) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= d) return;
+    if (means) means[j] = s0 * mean[j];
+    if (stds) stds[j] = s0 * sqrt(fmax(var[j], 0.0));
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+#define HIPCHK(ctx, call)                                                                        \
+    do {                                                                                         \
+        hipError_t e__ = (call);                                                                 \
+        if (e__ != hipSuccess) {                                                                 \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                     \
+            return -2;                                                                           \
+        }                                                                                        \
+    } while (0)
+
+static inline int round_up(int x, int q) { return (x + q - 1) / q * q; }
+
+static double nordsieck_scale(int nu, int a, double dt) {  // base/iwp.py:55-62
+    double fact = 1.0;
+    for (int q = 2; q <= nu - a; ++q) fact *= q;
+    return std::pow(std::fabs(dt), nu - a + 0.5) / fact;
+}
+
+}  // namespace
+
+struct pnmol_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+};
+
+struct pnmol_filter {
+    pnmol_ctx* ctx = nullptr;
+    int d = 0, n = 0, nu = 0, nB = 0, m = 0, dp = 0, mp = 0, CB = 0, RBS = 0, RBW = 0, RT = 0, ellw = 0;
+    long Dp = 0;
+    IwpConsts iwp{};
+    int* ell_col = nullptr;
+    double* ell_val = nullptr;
+    double *Kg = nullptr, *rdiag = nullptr, *Rdense = nullptr, *shift = nullptr;
+    double *G = nullptr, *F = nullptr, *Linv = nullptr, *Ppred = nullptr, *mpred = nullptr, *zbuf = nullptr;
+    double *var = nullptr, *Sqinv = nullptr, *rec = nullptr, *xbuf = nullptr;
+    int* info = nullptr;
+    std::vector<double> sqdiag;
+    double sq_dt = -1.0;
+    // scratch state for ping-pong inside steps()
+    double *tmpP = nullptr, *tmpMean = nullptr;
+    double *rec_means = nullptr, *rec_stds = nullptr;
+    int rec_cap = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_ms = 0.f;
+};
+
+struct pnmol_state {
+    pnmol_filter* f = nullptr;
+    double* mean = nullptr;  // Dp
+    double* P = nullptr;     // Dp*Dp
+    double* var = nullptr;   // Dp   marginal variances, same frame as P
+    double t = 0.0;
+    double frame_dt = 0.0;  // 0 = raw coordinates, else Nordsieck frame of that dt
+};
+
+namespace {
+
+template <int N>
+int launch_step(pnmol_filter* f, const double* Pin, const double* min, double frame_dt, double dt, double* Pout,
+                double* mout, double* varout, int step_slot, double* means_out, double* stds_out) {
+    pnmol_ctx* ctx = f->ctx;
+    hipStream_t st = ctx->stream;
+    IwpConsts c = f->iwp;
+    for (int a = 0; a < f->n; ++a) {
+        const double so = frame_dt == 0.0 ? 1.0 : nordsieck_scale(f->nu, a, frame_dt);
+        c.ts[a] = so / nordsieck_scale(f->nu, a, dt);
+    }
+    MeasModel mm{f->ell_col, f->ell_val, f->ellw, f->d, f->m, f->dp, f->mp,
+                 nordsieck_scale(f->nu, 0, dt), nordsieck_scale(f->nu, 1, dt)};
+    const int dp = f->dp, mp = f->mp;
+    const long Dp = f->Dp;
+    double* rec = f->rec + 4L * step_slot;
+    int* info = f->info + step_slot;
+
+    k_predict<N><<<dim3(dp / 32, dp / 8), dim3(32, 8), 0, st>>>(Pin, f->Ppred, f->Kg, c, dp);
+    k_predict_mean<N><<<(dp + 255) / 256, 256, 0, st>>>(min, f->mpred, c, dp);
+    k_pht<<<dim3((mp + 255) / 256, (unsigned)Dp), 256, 0, st>>>(f->Ppred, f->G, mm, Dp);
+    k_zrow<<<(mp + 255) / 256, 256, 0, st>>>(f->mpred, f->shift, f->G, f->zbuf, mm, Dp);
+    k_sbuild<<<dim3((mp + 255) / 256, mp), 256, 0, st>>>(f->G, f->rdiag, f->Rdense, mm);
+    k_diag0<<<1, 256, 0, st>>>(f->G, f->F, f->Linv, mp, info);
+    for (int j = 0; j < f->CB; ++j) {
+        const int nrb = f->RT - (j + 1);
+        const int ncb = f->CB - 1 - j > 0 ? f->CB - 1 - j : 1;
+        k_panel<<<dim3(nrb, ncb), 256, 0, st>>>(f->G, f->F, f->Linv, mp, j, f->CB, f->RBS, info);
+    }
+    const double* W = f->F + (long)mp * mp;
+    const double* r = f->F + ((long)mp + Dp) * mp;
+    const bool have_sq = (f->Sqinv != nullptr && f->sq_dt == dt);
+    k_stats<<<1, 1024, 0, st>>>(r, f->zbuf, have_sq ? f->Sqinv : nullptr, rec, mp);
+    k_backsolve<<<1, 256, (mp + 256 + 32) * sizeof(double), st>>>(f->F, f->Linv, f->zbuf, rec, mp, f->CB, f->xbuf);
+    k_meanupd<<<(unsigned)((Dp + 3) / 4), 256, 0, st>>>(f->mpred, W, r, mout, mp, Dp);
+    k_downdate<N><<<dim3(dp / 16, dp / 16), 256, 0, st>>>(f->Ppred, W, Pout, varout, dp, mp);
+    if (means_out || stds_out)
+        k_readout<<<(f->d + 255) / 256, 256, 0, st>>>(mout, varout, means_out, stds_out,
+                                                      nordsieck_scale(f->nu, 0, dt), f->d);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        ctx->err = std::string("kernel launch: ") + hipGetErrorString(e);
+        return -2;
+    }
+    return 0;
+}
+
+int dispatch_step(pnmol_filter* f, const double* Pin, const double* min, double frame_dt, double dt, double* Pout,
+                  double* mout, double* varout, int slot, double* mo, double* so) {
+    switch (f->n) {
+        case 2: return launch_step<2>(f, Pin, min, frame_dt, dt, Pout, mout, varout, slot, mo, so);
+        case 3: return launch_step<3>(f, Pin, min, frame_dt, dt, Pout, mout, varout, slot, mo, so);
+        case 4: return launch_step<4>(f, Pin, min, frame_dt, dt, Pout, mout, varout, slot, mo, so);
+    }
+    return -1;
+}
+
+int ensure_rec(pnmol_filter* f, int k) {
+    if (k <= f->rec_cap) return 0;
+    pnmol_ctx* ctx = f->ctx;
+    if (f->rec) hipFree(f->rec);
+    if (f->info) hipFree(f->info);
+    if (f->rec_means) hipFree(f->rec_means);
+    if (f->rec_stds) hipFree(f->rec_stds);
+    f->rec = nullptr, f->info = nullptr, f->rec_means = nullptr, f->rec_stds = nullptr;
+    f->rec_cap = 0;
+    HIPCHK(ctx, hipMalloc(&f->rec, sizeof(double) * 4 * k));
+    HIPCHK(ctx, hipMalloc(&f->info, sizeof(int) * k));
+    HIPCHK(ctx, hipMalloc(&f->rec_means, sizeof(double) * (size_t)k * f->d));
+    HIPCHK(ctx, hipMalloc(&f->rec_stds, sizeof(double) * (size_t)k * f->d));
+    f->rec_cap = k;
+    return 0;
+}
+
+void fill_out(const pnmol_filter* f, const double* rec, int info, double t_new, bool have_sq, pnmol_step_out* o) {
+    o->t_new = t_new;
+    o->sigma2_whitened = rec[0] / f->m;
+    o->diffusion_squared_local = rec[1] / f->m;
+    o->error_sigma2 = have_sq ? rec[2] / f->m : std::nan("");
+    o->info = (info >= f->mp) ? -1 : info;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pnmol_abi_version(void) { return 1; }
+
+int pnmol_device_count(int* count) {
+    if (!count) return -1;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) {
+        *count = 0;
+        return -2;
+    }
+    *count = c;
+    return 0;
+}
+
+int pnmol_ctx_create(int device, pnmol_ctx** out) {
+    if (!out) return -1;
+    *out = nullptr;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess || device < 0 || device >= c) return -2;
+    if (hipSetDevice(device) != hipSuccess) return -2;
+    pnmol_ctx* ctx = new pnmol_ctx();
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return -2;
+    }
+    *out = ctx;
+    return 0;
+}
+
+int pnmol_ctx_destroy(pnmol_ctx* ctx) {
+    if (!ctx) return -1;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return 0;
+}
+
+int pnmol_ctx_synchronize(pnmol_ctx* ctx) {
+    if (!ctx) return -1;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+const char* pnmol_last_error(pnmol_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_filter** out) {
+    if (!ctx || !desc || !out) return -1;
+    *out = nullptr;
+    const int d = desc->d, nu = desc->num_derivatives, nB = desc->nB, n = nu + 1;
+    if (d < 1 || nu < 1 || n > MAXN || nB < 0 || !desc->L || !desc->E_sqrtm || !desc->Gamma ||
+        (nB > 0 && (!desc->B || !desc->R_sqrtm))) {
+        ctx->err = "pnmol_filter_create: bad descriptor (need d>=1, 1<=nu<=3, non-null L/B/E_sqrtm/R_sqrtm/Gamma)";
+        return -1;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    pnmol_filter* f = new pnmol_filter();
+    f->ctx = ctx;
+    f->d = d, f->nu = nu, f->n = n, f->nB = nB, f->m = d + nB;
+    f->dp = round_up(d, NB), f->mp = round_up(f->m, NB);
+    f->Dp = (long)n * f->dp;
+    f->CB = f->mp / NB, f->RBS = f->mp / NB, f->RBW = (int)(f->Dp / NB), f->RT = f->RBS + f->RBW + 1;
+    const int dp = f->dp, mp = f->mp, m = f->m;
+    const long Dp = f->Dp;
+
+    // IWP constants, base/iwp.py:13-30: A1 = flip(pascal lower), Q1 = flip(hilbert)
+    for (int a = 0; a < n; ++a)
+        for (int b = 0; b < n; ++b) {
+            const int ia = n - 1 - a, ib = n - 1 - b;  // flip both axes
+            double binom = 0.0;
+            if (ib <= ia) {
+                binom = 1.0;
+                for (int q = 1; q <= ib; ++q) binom = binom * (ia - ib + q) / q;
+            }
+            f->iwp.A1[a * MAXN + b] = binom;
+            f->iwp.Q1[a * MAXN + b] = 1.0 / (ia + ib + 1.0);
+        }
+
+    // Hv = [-L; B] in ELL, rows padded to mp
+    std::vector<int> nnz(m, 0);
+    for (int i = 0; i < d; ++i)
+        for (int k = 0; k < d; ++k) nnz[i] += desc->L[(long)i * d + k] != 0.0;
+    for (int r = 0; r < nB; ++r)
+        for (int k = 0; k < d; ++k) nnz[d + r] += desc->B[(long)r * d + k] != 0.0;
+    int w = 1;
+    for (int i = 0; i < m; ++i) w = nnz[i] > w ? nnz[i] : w;
+    f->ellw = w;
+    std::vector<int> ecol((size_t)w * mp, -1);
+    std::vector<double> eval((size_t)w * mp, 0.0);
+    for (int i = 0; i < m; ++i) {
+        int e = 0;
+        for (int k = 0; k < d; ++k) {
+            const double v = i < d ? -desc->L[(long)i * d + k] : desc->B[(long)(i - d) * d + k];
+            if (v != 0.0) {
+                ecol[(size_t)e * mp + i] = k;  // state index (0, k) = k
+                eval[(size_t)e * mp + i] = v;
+                ++e;
+            }
+        }
+    }
+    // R = blockdiag(E E^T, Rb Rb^T): diagonal fast path, dense otherwise
+    bool diag = true;
+    for (int i = 0; i < d && diag; ++i)
+        for (int k = 0; k < d; ++k)
+            if (i != k && desc->E_sqrtm[(long)i * d + k] != 0.0) {
+                diag = false;
+                break;
+            }
+    for (int i = 0; i < nB && diag; ++i)
+        for (int k = 0; k < nB; ++k)
+            if (i != k && desc->R_sqrtm[(long)i * nB + k] != 0.0) {
+                diag = false;
+                break;
+            }
+    std::vector<double> rdiag(mp, 0.0), Rd;
+    if (diag) {
+        for (int i = 0; i < d; ++i) rdiag[i] = desc->E_sqrtm[(long)i * d + i] * desc->E_sqrtm[(long)i * d + i];
+        for (int i = 0; i < nB; ++i) rdiag[d + i] = desc->R_sqrtm[(long)i * nB + i] * desc->R_sqrtm[(long)i * nB + i];
+    } else {
+        Rd.assign((size_t)mp * mp, 0.0);
+        for (int i = 0; i < d; ++i)
+            for (int k = 0; k <= i; ++k) {
+                double s = 0.0;
+                for (int q = 0; q < d; ++q) s += desc->E_sqrtm[(long)i * d + q] * desc->E_sqrtm[(long)k * d + q];
+                Rd[(size_t)i * mp + k] = Rd[(size_t)k * mp + i] = s;
+            }
+        for (int i = 0; i < nB; ++i)
+            for (int k = 0; k <= i; ++k) {
+                double s = 0.0;
+                for (int q = 0; q < nB; ++q) s += desc->R_sqrtm[(long)i * nB + q] * desc->R_sqrtm[(long)k * nB + q];
+                Rd[(size_t)(d + i) * mp + d + k] = Rd[(size_t)(d + k) * mp + d + i] = s;
+            }
+    }
+    // K = Gamma Gamma^T (white.py:84-85, base/iwp.py:49-52), padded
+    std::vector<double> Kg((size_t)dp * dp, 0.0);
+    for (int i = 0; i < d; ++i)
+        for (int k = 0; k <= i; ++k) {
+            double s = 0.0;
+            for (int q = 0; q <= k; ++q) s += desc->Gamma[(long)i * d + q] * desc->Gamma[(long)k * d + q];
+            Kg[(size_t)i * dp + k] = Kg[(size_t)k * dp + i] = s;
+        }
+
+    auto fail = [&](int code) {
+        pnmol_filter_destroy(f);
+        return code;
+    };
+#define FCHK(call)                                                                    \
+    do {                                                                              \
+        hipError_t e__ = (call);                                                      \
+        if (e__ != hipSuccess) {                                                      \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e__);            \
+            return fail(e__ == hipErrorOutOfMemory ? -4 : -2);                        \
+        }                                                                             \
+    } while (0)
+    const size_t tall = (size_t)f->RT * NB * mp;
+    FCHK(hipMalloc(&f->ell_col, sizeof(int) * ecol.size()));
+    FCHK(hipMalloc(&f->ell_val, sizeof(double) * eval.size()));
+    FCHK(hipMalloc(&f->Kg, sizeof(double) * Kg.size()));
+    FCHK(hipMalloc(&f->rdiag, sizeof(double) * mp));
+    FCHK(hipMalloc(&f->shift, sizeof(double) * mp));
+    FCHK(hipMalloc(&f->G, sizeof(double) * tall));
+    FCHK(hipMalloc(&f->F, sizeof(double) * tall));
+    FCHK(hipMalloc(&f->Linv, sizeof(double) * (size_t)f->CB * NB * NB));
+    FCHK(hipMalloc(&f->Ppred, sizeof(double) * (size_t)Dp * Dp));
+    FCHK(hipMalloc(&f->tmpP, sizeof(double) * (size_t)Dp * Dp));
+    FCHK(hipMalloc(&f->mpred, sizeof(double) * Dp));
+    FCHK(hipMalloc(&f->tmpMean, sizeof(double) * Dp));
+    FCHK(hipMalloc(&f->var, sizeof(double) * Dp));
+    FCHK(hipMalloc(&f->zbuf, sizeof(double) * mp));
+    FCHK(hipMalloc(&f->xbuf, sizeof(double) * mp));
+    FCHK(hipMemcpy(f->ell_col, ecol.data(), sizeof(int) * ecol.size(), hipMemcpyHostToDevice));
+    FCHK(hipMemcpy(f->ell_val, eval.data(), sizeof(double) * eval.size(), hipMemcpyHostToDevice));
+    FCHK(hipMemcpy(f->Kg, Kg.data(), sizeof(double) * Kg.size(), hipMemcpyHostToDevice));
+    FCHK(hipMemcpy(f->rdiag, rdiag.data(), sizeof(double) * mp, hipMemcpyHostToDevice));
+    if (!diag) {
+        FCHK(hipMalloc(&f->Rdense, sizeof(double) * Rd.size()));
+        FCHK(hipMemcpy(f->Rdense, Rd.data(), sizeof(double) * Rd.size(), hipMemcpyHostToDevice));
+    }
+    FCHK(hipMemset(f->shift, 0, sizeof(double) * mp));
+    FCHK(hipMemset(f->G, 0, sizeof(double) * tall));
+    FCHK(hipMemset(f->F, 0, sizeof(double) * tall));
+    FCHK(hipMemset(f->var, 0, sizeof(double) * Dp));
+    FCHK(hipMemset(f->tmpP, 0, sizeof(double) * (size_t)Dp * Dp));
+    FCHK(hipMemset(f->tmpMean, 0, sizeof(double) * Dp));
+    FCHK(hipEventCreate(&f->ev0));
+    FCHK(hipEventCreate(&f->ev1));
+#undef FCHK
+    if (ensure_rec(f, 1) != 0) return fail(-2);
+    *out = f;
+    return 0;
+}
+
+int pnmol_filter_destroy(pnmol_filter* f) {
+    if (!f) return -1;
+    hipSetDevice(f->ctx->device);
+    void* ptrs[] = {f->ell_col, f->ell_val, f->Kg,   f->rdiag,   f->Rdense, f->shift,     f->G,        f->F,
+                    f->Linv,    f->Ppred,   f->mpred, f->zbuf,   f->var,    f->Sqinv,     f->rec,      f->xbuf,
+                    f->info,    f->tmpP,    f->tmpMean, f->rec_means, f->rec_stds};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    if (f->ev0) hipEventDestroy(f->ev0);
+    if (f->ev1) hipEventDestroy(f->ev1);
+    delete f;
+    return 0;
+}
+
+int pnmol_filter_dims(const pnmol_filter* f, int* d, int* n, int* m, int* dp, int* mp) {
+    if (!f) return -1;
+    if (d) *d = f->d;
+    if (n) *n = f->n;
+    if (m) *m = f->m;
+    if (dp) *dp = f->dp;
+    if (mp) *mp = f->mp;
+    return 0;
+}
+
+int pnmol_filter_set_error_model(pnmol_filter* f, double dt, const double* Sq_inv, const double* Sq_diag) {
+    if (!f || !Sq_inv || !Sq_diag || !(dt > 0.0)) return -1;
+    pnmol_ctx* ctx = f->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int m = f->m, mp = f->mp;
+    std::vector<double> pad((size_t)mp * mp, 0.0);
+    for (int i = 0; i < m; ++i) std::memcpy(&pad[(size_t)i * mp], Sq_inv + (size_t)i * m, sizeof(double) * m);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (!f->Sqinv) HIPCHK(ctx, hipMalloc(&f->Sqinv, sizeof(double) * pad.size()));
+    HIPCHK(ctx, hipMemcpy(f->Sqinv, pad.data(), sizeof(double) * pad.size(), hipMemcpyHostToDevice));
+    f->sqdiag.assign(Sq_diag, Sq_diag + m);
+    f->sq_dt = dt;
+    return 0;
+}
+
+int pnmol_state_create(pnmol_filter* f, pnmol_state** out) {
+    if (!f || !out) return -1;
+    *out = nullptr;
+    pnmol_ctx* ctx = f->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    pnmol_state* s = new pnmol_state();
+    s->f = f;
+    const size_t Dp = (size_t)f->Dp;
+    if (hipMalloc(&s->mean, sizeof(double) * Dp) != hipSuccess || hipMalloc(&s->var, sizeof(double) * Dp) != hipSuccess ||
+        hipMalloc(&s->P, sizeof(double) * Dp * Dp) != hipSuccess) {
+        ctx->err = "pnmol_state_create: hipMalloc failed";
+        pnmol_state_destroy(s);
+        return -4;
+    }
+    hipMemset(s->mean, 0, sizeof(double) * Dp);
+    hipMemset(s->var, 0, sizeof(double) * Dp);
+    hipMemset(s->P, 0, sizeof(double) * Dp * Dp);
+    *out = s;
+    return 0;
+}
+
+int pnmol_state_destroy(pnmol_state* s) {
+    if (!s) return -1;
+    hipSetDevice(s->f->ctx->device);
+    if (s->mean) hipFree(s->mean);
+    if (s->var) hipFree(s->var);
+    if (s->P) hipFree(s->P);
+    delete s;
+    return 0;
+}
+
+int pnmol_state_clone(const pnmol_state* s, pnmol_state** out) {
+    if (!s || !out) return -1;
+    int rc = pnmol_state_create(s->f, out);
+    if (rc != 0) return rc;
+    pnmol_ctx* ctx = s->f->ctx;
+    pnmol_state* o = *out;
+    const size_t Dp = (size_t)s->f->Dp;
+    HIPCHK(ctx, hipMemcpyAsync(o->mean, s->mean, sizeof(double) * Dp, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(o->var, s->var, sizeof(double) * Dp, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(o->P, s->P, sizeof(double) * Dp * Dp, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    o->t = s->t, o->frame_dt = s->frame_dt;
+    return 0;
+}
+
+int pnmol_state_set(pnmol_state* s, double t, const double* mean_nd, const double* cov_DD) {
+    if (!s || !mean_nd || !cov_DD) return -1;
+    pnmol_filter* f = s->f;
+    pnmol_ctx* ctx = f->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int n = f->n, d = f->d, dp = f->dp;
+    const long D = (long)n * d, Dp = f->Dp;
+    std::vector<double> hm((size_t)Dp, 0.0), hv((size_t)Dp, 0.0), hP((size_t)Dp * Dp, 0.0);
+    for (int a = 0; a < n; ++a)
+        for (int j = 0; j < d; ++j) {
+            hm[(size_t)a * dp + j] = mean_nd[(size_t)a * d + j];
+            hv[(size_t)a * dp + j] = cov_DD[((size_t)j * n + a) * D + (size_t)j * n + a];
+        }
+    for (int a = 0; a < n; ++a)
+        for (int j = 0; j < d; ++j) {
+            const double* src = cov_DD + ((size_t)j * n + a) * D;
+            double* dst = &hP[((size_t)a * dp + j) * Dp];
+            for (int b = 0; b < n; ++b)
+                for (int k = 0; k < d; ++k) dst[(size_t)b * dp + k] = src[(size_t)k * n + b];
+        }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(s->mean, hm.data(), sizeof(double) * hm.size(), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(s->var, hv.data(), sizeof(double) * hv.size(), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(s->P, hP.data(), sizeof(double) * hP.size(), hipMemcpyHostToDevice));
+    s->t = t;
+    s->frame_dt = 0.0;
+    return 0;
+}
+
+int pnmol_state_get_time(const pnmol_state* s, double* t) {
+    if (!s || !t) return -1;
+    *t = s->t;
+    return 0;
+}
+
+static void frame_scales(const pnmol_state* s, double* sc) {
+    for (int a = 0; a < s->f->n; ++a) sc[a] = s->frame_dt == 0.0 ? 1.0 : nordsieck_scale(s->f->nu, a, s->frame_dt);
+}
+
+int pnmol_state_get_mean(const pnmol_state* s, double* mean_nd) {
+    if (!s || !mean_nd) return -1;
+    pnmol_filter* f = s->f;
+    pnmol_ctx* ctx = f->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::vector<double> hm((size_t)f->Dp);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(hm.data(), s->mean, sizeof(double) * hm.size(), hipMemcpyDeviceToHost));
+    double sc[MAXN];
+    frame_scales(s, sc);
+    for (int a = 0; a < f->n; ++a)
+        for (int j = 0; j < f->d; ++j) mean_nd[(size_t)a * f->d + j] = sc[a] * hm[(size_t)a * f->dp + j];
+    return 0;
+}
+
+int pnmol_state_get_marginal_var(const pnmol_state* s, double* var_nd) {
+    if (!s || !var_nd) return -1;
+    pnmol_filter* f = s->f;
+    pnmol_ctx* ctx = f->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::vector<double> hv((size_t)f->Dp);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(hv.data(), s->var, sizeof(double) * hv.size(), hipMemcpyDeviceToHost));
+    double sc[MAXN];
+    frame_scales(s, sc);
+    for (int a = 0; a < f->n; ++a)
+        for (int j = 0; j < f->d; ++j) var_nd[(size_t)a * f->d + j] = sc[a] * sc[a] * hv[(size_t)a * f->dp + j];
+    return 0;
+}
+
+int pnmol_state_get_cov(const pnmol_state* s, double* cov_DD) {
+    if (!s || !cov_DD) return -1;
+    pnmol_filter* f = s->f;
+    pnmol_ctx* ctx = f->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int n = f->n, d = f->d, dp = f->dp;
+    const long D = (long)n * d, Dp = f->Dp;
+    std::vector<double> hP((size_t)Dp * Dp);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(hP.data(), s->P, sizeof(double) * hP.size(), hipMemcpyDeviceToHost));
+    double sc[MAXN];
+    frame_scales(s, sc);
+    for (int a = 0; a < n; ++a)
+        for (int j = 0; j < d; ++j) {
+            double* dst = cov_DD + ((size_t)j * n + a) * D;
+            const double* src = &hP[((size_t)a * dp + j) * Dp];
+            for (int b = 0; b < n; ++b)
+                for (int k = 0; k < d; ++k) dst[(size_t)k * n + b] = sc[a] * sc[b] * src[(size_t)b * dp + k];
+        }
+    return 0;
+}
+
+int pnmol_filter_step(pnmol_filter* f, const pnmol_state* in, double dt, pnmol_state* out, pnmol_step_out* info,
+                      double* error_estimate_d) {
+    if (!f || !in || !out || in == out || in->f != f || out->f != f || !(dt > 0.0)) {
+        if (f) f->ctx->err = "pnmol_filter_step: bad argument (null, aliasing states, foreign state or dt <= 0)";
+        return -1;
+    }
+    pnmol_ctx* ctx = f->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemsetAsync(f->info, 0x7f, sizeof(int), ctx->stream));
+    int rc = dispatch_step(f, in->P, in->mean, in->frame_dt, dt, out->P, out->mean, out->var, 0, nullptr, nullptr);
+    if (rc != 0) return rc;
+    double rec[4];
+    int inf = 0;
+    HIPCHK(ctx, hipMemcpyAsync(rec, f->rec, sizeof(rec), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&inf, f->info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    out->t = in->t + dt;
+    out->frame_dt = dt;
+    const bool have_sq = (f->Sqinv != nullptr && f->sq_dt == dt);
+    pnmol_step_out o;
+    fill_out(f, rec, inf, out->t, have_sq, &o);
+    if (info) *info = o;
+    if (error_estimate_d) {
+        // white.py:117-129: error = dt * sqrt(diag Sq) * sigma, truncated to the d PDE rows
+        for (int i = 0; i < f->d; ++i)
+            error_estimate_d[i] = have_sq ? dt * std::sqrt(f->sqdiag[i]) * std::sqrt(o.error_sigma2) : std::nan("");
+    }
+    if (o.info >= 0) {
+        ctx->err = "innovation matrix not positive definite at pivot " + std::to_string(o.info);
+        return -3;
+    }
+    return 0;
+}
+
+int pnmol_filter_steps(pnmol_filter* f, pnmol_state* s, int k, double dt, double* means_kd, double* stds_kd,
+                       pnmol_step_out* info_k) {
+    if (!f || !s || s->f != f || k < 1 || !(dt > 0.0)) {
+        if (f) f->ctx->err = "pnmol_filter_steps: bad argument";
+        return -1;
+    }
+    pnmol_ctx* ctx = f->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_rec(f, k);
+    if (rc != 0) return rc;
+    hipStream_t st = ctx->stream;
+    HIPCHK(ctx, hipMemsetAsync(f->info, 0x7f, sizeof(int) * k, st));
+    HIPCHK(ctx, hipEventRecord(f->ev0, st));
+    double *curP = s->P, *curM = s->mean, *nxtP = f->tmpP, *nxtM = f->tmpMean;
+    double frame = s->frame_dt;
+    for (int it = 0; it < k; ++it) {
+        rc = dispatch_step(f, curP, curM, frame, dt, nxtP, nxtM, s->var, it, f->rec_means + (size_t)it * f->d,
+                           f->rec_stds + (size_t)it * f->d);
+        if (rc != 0) return rc;
+        double* t;
+        t = curP, curP = nxtP, nxtP = t;
+        t = curM, curM = nxtM, nxtM = t;
+        frame = dt;
+    }
+    HIPCHK(ctx, hipEventRecord(f->ev1, st));
+    // the filter owns tmpP/tmpMean: after an odd number of steps the result lives there -> swap ownership
+    if (curP != s->P) {
+        f->tmpP = s->P, f->tmpMean = s->mean;
+        s->P = curP, s->mean = curM;
+    }
+    std::vector<double> rec((size_t)4 * k);
+    std::vector<int> inf(k);
+    HIPCHK(ctx, hipMemcpyAsync(rec.data(), f->rec, sizeof(double) * rec.size(), hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(inf.data(), f->info, sizeof(int) * k, hipMemcpyDeviceToHost, st));
+    if (means_kd)
+        HIPCHK(ctx, hipMemcpyAsync(means_kd, f->rec_means, sizeof(double) * (size_t)k * f->d, hipMemcpyDeviceToHost, st));
+    if (stds_kd)
+        HIPCHK(ctx, hipMemcpyAsync(stds_kd, f->rec_stds, sizeof(double) * (size_t)k * f->d, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    HIPCHK(ctx, hipEventElapsedTime(&f->last_ms, f->ev0, f->ev1));
+    const bool have_sq = (f->Sqinv != nullptr && f->sq_dt == dt);
+    int bad = -1;
+    double t = s->t;
+    for (int it = 0; it < k; ++it) {
+        t += dt;
+        pnmol_step_out o;
+        fill_out(f, &rec[(size_t)4 * it], inf[it], t, have_sq, &o);
+        if (info_k) info_k[it] = o;
+        if (o.info >= 0 && bad < 0) bad = it;
+    }
+    s->t = t;
+    s->frame_dt = dt;
+    if (bad >= 0) {
+        ctx->err = "innovation matrix not positive definite in step " + std::to_string(bad);
+        return -3;
+    }
+    return 0;
+}
+
+int pnmol_filter_last_steps_ms(pnmol_filter* f, float* ms) {
+    if (!f || !ms) return -1;
+    *ms = f->last_ms;
+    return 0;
+}
+
+int pnmol_filter_debug_read(pnmol_filter* f, int which, double* dst, long count) {
+    if (!f || !dst || count < 0) return -1;
+    pnmol_ctx* ctx = f->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const double* src = nullptr;
+    long avail = 0;
+    const long tall = (long)f->RT * NB * f->mp;
+    switch (which) {
+        case 0: src = f->Ppred, avail = f->Dp * f->Dp; break;
+        case 1: src = f->G, avail = tall; break;
+        case 2: src = f->F, avail = tall; break;
+        case 3: src = f->mpred, avail = f->Dp; break;
+        case 4: src = f->zbuf, avail = f->mp; break;
+        default: return -1;
+    }
+    if (count > avail) return -1;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(dst, src, sizeof(double) * count, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,252 @@
+"""ctypes binding of `libpnmol_hip.so` (C ABI declared in include/pnmol_hip.h).
+
+There is no CPU fallback: if the library or a GPU is missing, the solver classes raise.
+"""
+
+import ctypes
+import os
+import pathlib
+
+import numpy as np
+
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+_HERE = pathlib.Path(__file__).resolve().parent
+LIB_PATH = pathlib.Path(os.environ.get("PNMOL_HIP_LIB", _HERE.parent / "lib" / "libpnmol_hip.so"))
+
+
+class PnmolHipError(RuntimeError):
+    """A call into libpnmol_hip.so failed."""
+
+
+class StepOut(ctypes.Structure):
+    _fields_ = [
+        ("t_new", ctypes.c_double),
+        ("diffusion_squared_local", ctypes.c_double),
+        ("sigma2_whitened", ctypes.c_double),
+        ("error_sigma2", ctypes.c_double),
+        ("info", ctypes.c_int),
+    ]
+
+
+class FilterDesc(ctypes.Structure):
+    _fields_ = [
+        ("d", ctypes.c_int),
+        ("num_derivatives", ctypes.c_int),
+        ("nB", ctypes.c_int),
+        ("L", _c_double_p),
+        ("B", _c_double_p),
+        ("E_sqrtm", _c_double_p),
+        ("R_sqrtm", _c_double_p),
+        ("Gamma", _c_double_p),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/pnmol_hip.h declares
+_vp = ctypes.c_void_p
+SYMBOLS = {
+    "pnmol_abi_version": (ctypes.c_int, []),
+    "pnmol_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    "pnmol_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
+    "pnmol_ctx_destroy": (ctypes.c_int, [_vp]),
+    "pnmol_ctx_synchronize": (ctypes.c_int, [_vp]),
+    "pnmol_last_error": (ctypes.c_char_p, [_vp]),
+    "pnmol_filter_create": (ctypes.c_int, [_vp, ctypes.POINTER(FilterDesc), ctypes.POINTER(_vp)]),
+    "pnmol_filter_destroy": (ctypes.c_int, [_vp]),
+    "pnmol_filter_set_error_model": (ctypes.c_int, [_vp, ctypes.c_double, _c_double_p, _c_double_p]),
+    "pnmol_state_create": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
+    "pnmol_state_destroy": (ctypes.c_int, [_vp]),
+    "pnmol_state_clone": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
+    "pnmol_state_set": (ctypes.c_int, [_vp, ctypes.c_double, _c_double_p, _c_double_p]),
+    "pnmol_state_get_time": (ctypes.c_int, [_vp, _c_double_p]),
+    "pnmol_state_get_mean": (ctypes.c_int, [_vp, _c_double_p]),
+    "pnmol_state_get_cov": (ctypes.c_int, [_vp, _c_double_p]),
+    "pnmol_state_get_marginal_var": (ctypes.c_int, [_vp, _c_double_p]),
+    "pnmol_filter_step": (ctypes.c_int, [_vp, _vp, ctypes.c_double, _vp, ctypes.POINTER(StepOut), _c_double_p]),
+    "pnmol_filter_steps": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_double, _c_double_p, _c_double_p,
+                                          ctypes.POINTER(StepOut)]),
+    "pnmol_filter_last_steps_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
+    "pnmol_filter_debug_read": (ctypes.c_int, [_vp, ctypes.c_int, _c_double_p, ctypes.c_long]),
+    "pnmol_filter_dims": (ctypes.c_int, [_vp] + [ctypes.POINTER(ctypes.c_int)] * 5),
+}
+
+_lib = None
+
+
+def load_library():
+    """Load the shared library (no GPU needed for this) and declare all prototypes."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise PnmolHipError(
+                f"{LIB_PATH} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
+                "pnmol has no CPU fallback for the filter step."
+            )
+        lib = ctypes.CDLL(str(LIB_PATH))
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(_c_double_p)
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    if shape is not None and a.shape != shape:
+        raise ValueError(f"expected shape {shape}, got {a.shape}")
+    return a
+
+
+class Context:
+    """One HIP device + stream (`pnmol_ctx`)."""
+
+    _cache = {}
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        n = ctypes.c_int(0)
+        rc = self.lib.pnmol_device_count(ctypes.byref(n))
+        if rc != 0 or n.value < 1:
+            raise PnmolHipError("no HIP device visible: the PNMOL filter step needs an AMD GPU (MI355X / gfx950)")
+        h = _vp()
+        rc = self.lib.pnmol_ctx_create(int(device), ctypes.byref(h))
+        if rc != 0:
+            raise PnmolHipError(f"pnmol_ctx_create(device={device}) failed with {rc}")
+        self.handle, self.device = h, int(device)
+
+    @classmethod
+    def default(cls, device=None):
+        if device is None:
+            device = int(os.environ.get("PNMOL_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+            n = ctypes.c_int(0)
+            load_library().pnmol_device_count(ctypes.byref(n))
+            if n.value > 0:
+                device %= n.value
+        if device not in cls._cache:
+            cls._cache[device] = cls(device)
+        return cls._cache[device]
+
+    def check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.pnmol_last_error(self.handle)
+            raise PnmolHipError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def synchronize(self):
+        self.check(self.lib.pnmol_ctx_synchronize(self.handle), "pnmol_ctx_synchronize")
+
+
+class Filter:
+    """`pnmol_filter`: the measurement/prior model of one discretised PDE on the device."""
+
+    def __init__(self, ctx, *, L, B, E_sqrtm, R_sqrtm, Gamma, num_derivatives):
+        self.ctx, self.lib = ctx, ctx.lib
+        d = L.shape[0]
+        nB = B.shape[0]
+        self._keep = [_f64(L, (d, d)), _f64(B, (nB, d)), _f64(E_sqrtm, (d, d)), _f64(R_sqrtm, (nB, nB)),
+                      _f64(Gamma, (d, d))]
+        desc = FilterDesc(d, int(num_derivatives), nB, *[_dp(a) for a in self._keep])
+        h = _vp()
+        ctx.check(self.lib.pnmol_filter_create(ctx.handle, ctypes.byref(desc), ctypes.byref(h)), "pnmol_filter_create")
+        self.handle = h
+        self.d, self.n, self.nB, self.m = d, int(num_derivatives) + 1, nB, d + nB
+        self.error_model_dt = None
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            self.lib.pnmol_filter_destroy(h)
+
+    def dims(self):
+        v = [ctypes.c_int(0) for _ in range(5)]
+        self.lib.pnmol_filter_dims(self.handle, *[ctypes.byref(x) for x in v])
+        return dict(zip(("d", "n", "m", "dp", "mp"), (x.value for x in v)))
+
+    def set_error_model(self, dt, Sq_inv, Sq_diag):
+        a, b = _f64(Sq_inv, (self.m, self.m)), _f64(Sq_diag, (self.m,))
+        self.ctx.check(self.lib.pnmol_filter_set_error_model(self.handle, float(dt), _dp(a), _dp(b)),
+                       "pnmol_filter_set_error_model")
+        self.error_model_dt = float(dt)
+
+    def new_state(self):
+        return State(self)
+
+    def step(self, state_in, dt, want_error=True):
+        out = State(self)
+        info = StepOut()
+        err = np.empty(self.d) if want_error else None
+        rc = self.lib.pnmol_filter_step(self.handle, state_in.handle, float(dt), out.handle, ctypes.byref(info),
+                                        _dp(err) if want_error else None)
+        self.ctx.check(rc, "pnmol_filter_step")
+        return out, info, err
+
+    def steps(self, state, k, dt, want_means=True, want_stds=True):
+        means = np.empty((k, self.d)) if want_means else None
+        stds = np.empty((k, self.d)) if want_stds else None
+        infos = (StepOut * k)()
+        rc = self.lib.pnmol_filter_steps(self.handle, state.handle, int(k), float(dt),
+                                         _dp(means) if want_means else None, _dp(stds) if want_stds else None, infos)
+        self.ctx.check(rc, "pnmol_filter_steps")
+        return means, stds, infos
+
+    def last_steps_ms(self):
+        ms = ctypes.c_float(0.0)
+        self.lib.pnmol_filter_last_steps_ms(self.handle, ctypes.byref(ms))
+        return float(ms.value)
+
+    def debug_read(self, which, count):
+        out = np.empty(int(count))
+        self.ctx.check(self.lib.pnmol_filter_debug_read(self.handle, int(which), _dp(out), int(count)),
+                       "pnmol_filter_debug_read")
+        return out
+
+
+class State:
+    """`pnmol_state`: device-resident (t, mean, covariance) of one filter state."""
+
+    def __init__(self, flt, _handle=None):
+        self.filter, self.lib, self.ctx = flt, flt.lib, flt.ctx
+        if _handle is None:
+            _handle = _vp()
+            self.ctx.check(self.lib.pnmol_state_create(flt.handle, ctypes.byref(_handle)), "pnmol_state_create")
+        self.handle = _handle
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            self.lib.pnmol_state_destroy(h)
+
+    def clone(self):
+        h = _vp()
+        self.ctx.check(self.lib.pnmol_state_clone(self.handle, ctypes.byref(h)), "pnmol_state_clone")
+        return State(self.filter, h)
+
+    def set(self, t, mean_nd, cov_DD):
+        f = self.filter
+        D = f.n * f.d
+        a, b = _f64(mean_nd, (f.n, f.d)), _f64(cov_DD, (D, D))
+        self.ctx.check(self.lib.pnmol_state_set(self.handle, float(t), _dp(a), _dp(b)), "pnmol_state_set")
+
+    @property
+    def t(self):
+        t = ctypes.c_double(0.0)
+        self.lib.pnmol_state_get_time(self.handle, ctypes.byref(t))
+        return t.value
+
+    def mean(self):
+        out = np.empty((self.filter.n, self.filter.d))
+        self.ctx.check(self.lib.pnmol_state_get_mean(self.handle, _dp(out)), "pnmol_state_get_mean")
+        return out
+
+    def marginal_var(self):
+        out = np.empty((self.filter.n, self.filter.d))
+        self.ctx.check(self.lib.pnmol_state_get_marginal_var(self.handle, _dp(out)), "pnmol_state_get_marginal_var")
+        return out
+
+    def cov(self):
+        D = self.filter.n * self.filter.d
+        out = np.empty((D, D))
+        self.ctx.check(self.lib.pnmol_state_get_cov(self.handle, _dp(out)), "pnmol_state_get_cov")
+        return out

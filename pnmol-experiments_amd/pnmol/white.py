@@ -1,0 +1,216 @@
+"""White-noise EK1 PDE filters (reference: src/pnmol/white.py).
+
+`attempt_step` and the constant-step loop run on the GPU through libpnmol_hip.so in the
+covariance (Cholesky) form that the reference's own tests prove equivalent to its QR form
+(tests/test_base/test_sqrt.py:48-78).  There is no CPU implementation of the step in this package.
+
+Documented deviations from the reference's numbers:
+  * `cov_sqrtm` is a (non-triangular) factor of the same covariance; only C C^T is comparable.
+  * `diffusion_squared_local`: the reference evaluates |R1^-1 z|^2 / m with the QR factor R1 of the
+    innovation (white.py:125), whose row signs LAPACK chooses from the data; here the same formula is
+    evaluated with the Cholesky factor (positive diagonal).  `last_step_info.sigma2_whitened` holds
+    z^T S^-1 z / m.
+"""
+
+import numpy as np
+import scipy.linalg
+import scipy.sparse
+
+from . import _hip, pdefilter
+from .base import iwp, rv
+from .odetools import step as _step
+
+
+class _WhiteNoiseEK1Base(pdefilter.PDEFilter):
+    _device_filter = None
+    _device_pde = None
+    last_step_info = None
+
+    # ------------------------------------------------------------------ cold path
+    def initialize_iwp(self, pde):
+        """Gamma = chol(k(X, X^T)); IWP prior; E0, E1 (white.py:82-94)."""
+        X = pde.mesh_spatial.points
+        diffusion_state_sqrtm = np.linalg.cholesky(self.spatial_kernel(X, X.T))
+        prior = iwp.IntegratedWienerTransition(num_derivatives=self.num_derivatives,
+                                               wiener_process_dimension=pde.y0.shape[0],
+                                               wp_diffusion_sqrtm=diffusion_state_sqrtm)
+        return prior, prior.projection_matrix(0), prior.projection_matrix(1), diffusion_state_sqrtm
+
+    def _bind(self, pde, gamma):
+        ctx = _hip.Context.default()
+        self._device_filter = _hip.Filter(ctx, L=self._jacobian_plus_L(pde), B=pde.B, E_sqrtm=pde.E_sqrtm,
+                                          R_sqrtm=pde.R_sqrtm, Gamma=gamma, num_derivatives=self.num_derivatives)
+        self._device_pde = pde
+        self._gram = gamma @ gamma.T
+        self._error_models = {}
+
+    @staticmethod
+    def _jacobian_plus_L(pde):
+        return pde.L
+
+    def initialize(self, pde):
+        """Initial state: prior conditioned on y0 and on the PDE/BC residual at t0 (white.py:12-80).
+
+        The two updates of the reference have observation noise ~1e-20, which a plain covariance
+        update cannot resolve; here they are evaluated block-wise in closed form (the prior
+        Gamma Gamma^T (x) c^2 I is Kronecker, the derivative blocks decouple), every difference
+        written so that it does not cancel.  O(d^3) on the host, once per solve.
+        """
+        self.iwp, self.E0, self.E1, gamma = self.initialize_iwp(pde)
+        self._bind(pde, gamma)
+        n, d = self.num_derivatives + 1, pde.L.shape[0]
+        mean, blocks = self._initial_moments(pde)
+        cov = np.zeros((n * d, n * d))
+        for (a, b), blk in blocks.items():
+            cov[a::n, b::n] = blk
+        dev = self._device_filter.new_state()
+        dev.set(pde.t0, mean, cov)
+        return pdefilter.PDEFilterState(t=pde.t0, y=rv.DeviceMultivariateNormal(mean, dev), error_estimate=None,
+                                        reference_state=None, diffusion_squared_local=[])
+
+    def _initial_moments(self, pde):
+        n, d = self.num_derivatives + 1, pde.L.shape[0]
+        eps2 = 1e-10 ** 2                                       # (1e-10 I)(1e-10 I)^T, white.py:33-39
+        Kc = self.diffuse_prior_scale ** 2 * self._gram         # C0 C0^T = K (x) c^2 I, white.py:21-24
+        # update 1: observe E0 x = y0.  V0 = Kc - Kc S1^-1 Kc = eps2 Kc S1^-1 (no cancellation)
+        S1 = scipy.linalg.cho_factor(Kc + eps2 * np.eye(d), lower=True)
+        G1 = scipy.linalg.cho_solve(S1, Kc).T                   # Kc S1^-1
+        V0 = eps2 * 0.5 * (G1 + G1.T)
+        m0 = G1 @ pde.y0
+        # update 2 (white.py:42-58): rows [E1 - M E0 ; B E0], noise (E_bc + 1e-10 I)(...)^T, block diagonal
+        M, shift = self._linearize(pde, m0, pde.t0)
+        nB = pde.B.shape[0]
+        En = pde.E_sqrtm + 1e-10 * np.eye(d)
+        Rn = pde.R_sqrtm + 1e-10 * np.eye(nB)
+        Re, Rb = En @ En.T, Rn @ Rn.T
+        # (a) boundary rows involve derivative 0 only
+        if nB > 0:
+            Sb = pde.B @ V0 @ pde.B.T + Rb
+            Gb = np.linalg.solve(Sb, pde.B @ V0).T              # V0 B^T Sb^-1
+            m0 = m0 - Gb @ (pde.B @ m0)
+            V0 = V0 - Gb @ (pde.B @ V0)
+            V0 = 0.5 * (V0 + V0.T)
+        # (b) PDE rows: z = x1 - M x0 + shift, prior blockdiag(V0, Kc);  Sp = Kc + T, T tiny
+        T = M @ V0 @ M.T + Re
+        Sp = scipy.linalg.cho_factor(Kc + T, lower=True)
+        z = -M @ m0 + shift
+        Spz = scipy.linalg.cho_solve(Sp, z)
+        SpT = scipy.linalg.cho_solve(Sp, T)                     # Sp^-1 T
+        V0Mt = V0 @ M.T
+        mean = np.zeros((n, d))
+        mean[0] = m0 + V0Mt @ Spz
+        mean[1] = -(z - T @ Spz)                                # -Kc Sp^-1 z
+        P00 = V0 - V0Mt @ scipy.linalg.cho_solve(Sp, V0Mt.T)
+        P01 = V0Mt - V0Mt @ SpT                                 # V0 M^T Sp^-1 Kc
+        P11 = T - T @ SpT                                       # Kc - Kc Sp^-1 Kc
+        blocks = {(0, 0): 0.5 * (P00 + P00.T), (0, 1): P01, (1, 0): P01.T, (1, 1): 0.5 * (P11 + P11.T)}
+        for q in range(2, n):
+            blocks[(q, q)] = Kc
+        return mean, blocks
+
+    # ------------------------------------------------------------------ step-invariant error model
+    def _error_model(self, pde, dt):
+        """Sq^-1 and diag(Sq) of `estimate_error` (white.py:153-162) in the Nordsieck frame of dt."""
+        key = float(dt)
+        if key not in self._error_models:
+            d, nB = pde.L.shape[0], pde.B.shape[0]
+            s, _ = self.iwp.nordsieck_preconditioner_1d_raw(dt)
+            n = self.num_derivatives + 1
+            Q1 = np.flip(scipy.linalg.hilbert(n))
+            Hv = scipy.sparse.csr_matrix(np.vstack((-self._jacobian_plus_L(pde), pde.B)))
+            F1K = np.vstack((self._gram, np.zeros((nB, d))))    # [I;0] K
+            HvK = Hv @ self._gram
+            cross = (Hv @ F1K.T).T                              # F1 K Hv^T
+            Sq = Q1[1, 1] * s[1] ** 2 * np.hstack((F1K, np.zeros((d + nB, nB))))
+            Sq = Sq + Q1[0, 1] * s[0] * s[1] * (cross + cross.T) + Q1[0, 0] * s[0] ** 2 * (Hv @ HvK.T).T
+            Ebc = scipy.linalg.block_diag(pde.E_sqrtm, pde.R_sqrtm)
+            Sq = Sq + Ebc @ Ebc.T
+            Sq = 0.5 * (Sq + Sq.T)
+            inv = scipy.linalg.cho_solve(scipy.linalg.cho_factor(Sq, lower=True), np.eye(d + nB))
+            self._error_models = {key: (0.5 * (inv + inv.T), np.diag(Sq).copy())}
+        return self._error_models[key]
+
+    def _ensure_error_model(self, pde, dt):
+        if self._device_filter.error_model_dt != float(dt):
+            self._device_filter.set_error_model(dt, *self._error_model(pde, dt))
+
+    # ------------------------------------------------------------------ hot path
+    def _device_state_of(self, state, pde):
+        if self._device_filter is None or self._device_pde is not pde:
+            raise RuntimeError("call initialize(pde) before attempt_step (the device model is bound there)")
+        y = state.y
+        if isinstance(y, rv.DeviceMultivariateNormal) and y.device_state.filter is self._device_filter:
+            return y.device_state
+        dev = self._device_filter.new_state()                   # host-side state: upload mean and C C^T
+        C = np.asarray(y.cov_sqrtm)
+        dev.set(state.t, np.asarray(y.mean), C @ C.T)
+        return dev
+
+    def attempt_step(self, state, dt, pde):
+        """One predict + update + calibrate step on the GPU (white.py:96-146); `state` is not modified."""
+        dev_in = self._device_state_of(state, pde)
+        self._ensure_error_model(pde, dt)
+        dev_out, info, error = self._device_filter.step(dev_in, dt)
+        self.last_step_info = info
+        m_new = dev_out.mean()
+        new_state = pdefilter.PDEFilterState(
+            t=state.t + dt, error_estimate=error, reference_state=np.abs(m_new[0]),
+            y=rv.DeviceMultivariateNormal(m_new, dev_out), diffusion_squared_local=info.diffusion_squared_local)
+        return new_state, dict(num_f_evaluations=1, num_df_evaluations=1)
+
+    def solve_marginals(self, pde, *, num_steps=None):
+        """Constant-step solve that keeps everything on the device: returns
+        (t (T+1,), means (T+1,d), stds (T+1,d), diffusion_squared_local (T,), final PDEFilterState).
+
+        `means`/`stds` are `sol.mean[:, 0]` and sqrt(diag(cov) E0^T) of the reference's read-out
+        (experiments/figure1.py:76-80).  Steps follow the t-accumulation of the reference's loop
+        (pdefilter.py:140-160, :220-223), including a runt final step when sum(dt) lands short of tmax.
+        """
+        if not isinstance(self.steprule, _step.Constant):
+            raise TypeError("solve_marginals needs the Constant step rule")
+        state = self.initialize(pde)
+        dev = state.y.device_state
+        dt0 = self.steprule.first_dt(pde)
+        ts, dts, t, dt = [pde.t0], [], pde.t0, dt0
+        while t < pde.tmax and (num_steps is None or len(dts) < num_steps):
+            dts.append(dt)
+            t = t + dt
+            ts.append(t)
+            dt = min(dt0, pde.tmax - t)
+        means = [state.y.mean[0]]
+        stds = [np.sqrt(np.maximum(state.y.marginal_var[0], 0.0))]
+        sig = []
+        i = 0
+        while i < len(dts):                                     # runs of equal dt -> one device call each
+            j = i
+            while j < len(dts) and dts[j] == dts[i]:
+                j += 1
+            self._ensure_error_model(pde, dts[i])
+            mk, sk, infos = self._device_filter.steps(dev, j - i, dts[i])
+            means.extend(mk), stds.extend(sk)
+            sig.extend(o.diffusion_squared_local for o in infos)
+            i = j
+        m_final = dev.mean()
+        final = pdefilter.PDEFilterState(t=ts[-1], y=rv.DeviceMultivariateNormal(m_final, dev), error_estimate=None,
+                                         reference_state=np.abs(m_final[0]),
+                                         diffusion_squared_local=sig[-1] if sig else [])
+        return np.array(ts), np.array(means), np.array(stds), np.array(sig), final
+
+
+class LinearWhiteNoiseEK1(_WhiteNoiseEK1Base):
+    """EK1 for linear PDEs u_t = L u (white.py:169-186): H = [E1 - L E0 ; B E0], no shift."""
+
+    @staticmethod
+    def _linearize(pde, m_at, t):
+        return pde.L, np.zeros(pde.L.shape[0])
+
+
+class SemiLinearWhiteNoiseEK1(_WhiteNoiseEK1Base):
+    """EK1 for semilinear PDEs (white.py:189-208).  Scope row f2 ("next"): not built yet."""
+
+    @staticmethod
+    def _linearize(pde, m_at, t):
+        raise NotImplementedError("SemiLinearWhiteNoiseEK1 is scheduled after the linear path (DESIGN.md, row f2)")
+
+    def attempt_step(self, state, dt, pde):
+        raise NotImplementedError("SemiLinearWhiteNoiseEK1 is scheduled after the linear path (DESIGN.md, row f2)")

@@ -1,0 +1,123 @@
+"""GPU parity tests: HIP path (through the C ABI) vs the CPU oracle.  Run with -m gpu."""
+
+import numpy as np
+import pytest
+import scipy.linalg
+
+import pnmol_oracle as oracle
+from helpers import assert_mean_std_parity, make_pair, to_device_layout
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_internals(osolver, opde, state, dt):
+    """Intermediate quantities of one oracle step in the Nordsieck frame (white.py:97-123)."""
+    P, Pinv = osolver.iwp.nordsieck_preconditioner(dt)
+    A, Ql = osolver.iwp.preconditioned_discretize
+    m = Pinv @ state.y.mean.reshape(-1, order="F")
+    C = Pinv @ state.y.cov_sqrtm
+    mp = A @ m
+    Pm = A @ C @ C.T @ A.T + Ql @ Ql.T
+    z, H, E = osolver.evaluate_ode(opde, osolver.E0 @ P, osolver.E1 @ P, mp, state.t + dt)
+    S = H @ Pm @ H.T + E @ E.T
+    Ls = np.linalg.cholesky(S)
+    W = scipy.linalg.solve_triangular(Ls, H @ Pm, lower=True).T
+    r = scipy.linalg.solve_triangular(Ls, z, lower=True)
+    return dict(mp=mp, Pm=Pm, z=z, S=S, Ls=Ls, W=W, r=r)
+
+
+@pytest.mark.parametrize("N,nu,bcond", [(32, 2, "dirichlet"), (20, 1, "neumann"), (40, 3, "dirichlet")])
+def test_step_stages(hip_ctx, N, nu, bcond):
+    """Every stage of one step against the oracle: P-, z, Ls, W, r, then the posterior."""
+    dt = 2.0 ** -7
+    pde, solver, opde, osolver = make_pair(N, nu, dt, 4, bcond)
+    ostate = osolver.initialize(opde)
+    solver.initialize(pde)                       # binds the device model
+    flt = solver._device_filter
+    n, d = nu + 1, N
+    dims = flt.dims()
+    dp, mp, m = dims["dp"], dims["mp"], dims["m"]
+    dev = flt.new_state()
+    dev.set(0.0, ostate.y.mean, ostate.y.cov_sqrtm @ ostate.y.cov_sqrtm.T)
+    solver._ensure_error_model(pde, dt)
+    out, info, err = flt.step(dev, dt)
+    ref = _oracle_internals(osolver, opde, ostate, dt)
+
+    Dp = n * dp
+    Ppred = flt.debug_read(0, Dp * Dp).reshape(Dp, Dp)
+    np.testing.assert_allclose(Ppred, to_device_layout(ref["Pm"], n, d, dp), rtol=1e-12, atol=1e-13 * np.abs(ref["Pm"]).max())
+    z = flt.debug_read(4, mp)
+    np.testing.assert_allclose(z[:m], ref["z"], rtol=1e-10, atol=1e-12 * np.abs(ref["z"]).max())
+    assert np.all(z[m:] == 0)
+    rows = mp + Dp + 32
+    F = flt.debug_read(2, rows * mp).reshape(rows, mp)
+    np.testing.assert_allclose(F[:m, :m], ref["Ls"], rtol=1e-8, atol=1e-10 * np.abs(ref["Ls"]).max())
+    Wdev = F[mp:mp + Dp, :m]
+    Wref = np.zeros((Dp, m))
+    for a in range(n):
+        Wref[a * dp:a * dp + d] = ref["W"][a::n]
+    np.testing.assert_allclose(Wdev, Wref, rtol=1e-7, atol=1e-9 * np.abs(Wref).max())
+    np.testing.assert_allclose(F[mp + Dp, :m], ref["r"], rtol=1e-7, atol=1e-9 * np.abs(ref["r"]).max())
+
+    onew, _ = osolver.attempt_step(ostate, dt, opde)
+    np.testing.assert_allclose(out.mean(), onew.y.mean, rtol=1e-8, atol=1e-10 * np.abs(onew.y.mean).max())
+    ocov = onew.y.cov_sqrtm @ onew.y.cov_sqrtm.T
+    np.testing.assert_allclose(out.cov(), ocov, rtol=1e-6, atol=1e-9 * np.abs(ocov).max())
+    np.testing.assert_allclose(out.marginal_var().reshape(-1, order="F"), np.diag(ocov), rtol=1e-6,
+                               atol=1e-9 * np.abs(ocov).max())
+    assert info.info == -1
+    np.testing.assert_allclose(info.diffusion_squared_local, onew.diffusion_squared_local, rtol=1e-7)
+    np.testing.assert_allclose(info.sigma2_whitened, ref["r"] @ ref["r"] / m, rtol=1e-8)
+    np.testing.assert_allclose(err, onew.error_estimate, rtol=1e-7)
+
+
+@pytest.mark.parametrize("N,nu,K,bcond", [(32, 1, 100, "dirichlet"), (64, 2, 100, "dirichlet"),
+                                          (64, 2, 40, "neumann"), (256, 2, 8, "dirichlet")])
+def test_solve_marginals_parity(hip_ctx, N, nu, K, bcond):
+    """BASELINE configs 0/1 (+ Neumann): K steps of dt=2^-7, mean rtol 1e-5, std rtol 1e-4."""
+    dt = 2.0 ** -7
+    pde, solver, opde, osolver = make_pair(N, nu, dt, K, bcond)
+    t, means, stds, sig, final = solver.solve_marginals(pde)
+    osol = osolver.solve(opde)
+    omeans, ostds = oracle.read_mean_and_std(osol, osolver.E0)
+    assert len(t) == K + 1 and np.array_equal(t, osol.t)
+    assert_mean_std_parity(means, stds, omeans, ostds)
+    # calibrated read-out of figure1.py:19-23 with the sign-canonical diffusion
+    np.testing.assert_allclose(np.mean(sig), osol.diffusion_squared_calibrated, rtol=1e-6)
+
+
+@pytest.mark.parametrize("bcond", ["dirichlet", "neumann"])
+def test_solve_api_smoke_problem(hip_ctx, bcond):
+    """The reference's own smoke case (tests/test_pdefilter.py:15-64,141-146): N=6, dt=0.1, tmax=1 ->
+    11 steps incl. the runt step; here also checked numerically against the oracle."""
+    pde, solver, opde, osolver = make_pair(6, 2, 0.1, 10, bcond, dx=0.2)
+    pde.tmax = opde.tmax = 1.0
+    solver.spatial_kernel = __import__("pnmol").kernels.SquareExponential() + __import__("pnmol").kernels.WhiteNoise()
+    osolver.spatial_kernel = oracle.SquareExponential() + oracle.WhiteNoise()
+    sol = solver.solve(pde)
+    osol = osolver.solve(opde)
+    assert sol.info == osol.info and sol.info["num_steps"] == 11
+    assert np.array_equal(sol.t, osol.t)
+    assert not np.any(np.isnan(sol.mean)) and not np.any(np.isnan(sol.cov_sqrtm))
+    omeans, ostds = oracle.read_mean_and_std(osol, osolver.E0)
+    assert_mean_std_parity(sol.mean[:, 0], sol.marginal_std[:, 0], omeans, ostds)
+    np.testing.assert_allclose(sol.mean, osol.mean, rtol=1e-5, atol=1e-5 * np.abs(osol.mean).max())
+    # the factor is not unique; C C^T is
+    cov = sol.cov_sqrtm @ np.transpose(sol.cov_sqrtm, (0, 2, 1))
+    ocov = osol.cov_sqrtm @ np.transpose(osol.cov_sqrtm, (0, 2, 1))
+    np.testing.assert_allclose(cov, ocov, rtol=1e-4, atol=1e-7 * np.abs(ocov).max())
+    np.testing.assert_allclose(sol.diffusion_squared_calibrated, osol.diffusion_squared_calibrated, rtol=1e-6)
+
+
+def test_attempt_step_is_functional(hip_ctx):
+    """attempt_step must not modify its input state (the driver re-uses it after a rejection,
+    pdefilter.py:192-223)."""
+    pde, solver, _, _ = make_pair(24, 2, 2.0 ** -6, 4)
+    s0 = solver.initialize(pde)
+    before = s0.y.cov.copy()
+    a, _ = solver.attempt_step(s0, 2.0 ** -6, pde)
+    b, _ = solver.attempt_step(s0, 2.0 ** -6, pde)
+    assert np.array_equal(s0.y.cov, before)
+    assert np.array_equal(a.y.mean, b.y.mean) and np.array_equal(a.y.cov, b.y.cov)
+    c, _ = solver.attempt_step(s0, 2.0 ** -7, pde)      # a different dt from the same state
+    assert not np.array_equal(a.y.mean, c.y.mean)
