@@ -1,0 +1,158 @@
+"""bench.py -- filter steps/sec of the PNMOL white-noise EK1 hot path on MI355X.
+
+`python bench.py --gpus N --steps K --warmup W`  (N>1: launched by torch.distributed.run, one rank
+per GPU).  A "step" is one predict+update of the filter (white.py:96-146) on the 1-D heat problem
+N=512, nu=2 (BASELINE.json metric / configs).  Each rank owns ONE independent problem of the
+diffusion-coefficient sweep kappa_g = 0.01 * 10^(g/7): weak scaling, no collective
+in the data path; RCCL only gathers the per-rank read-outs at the end.
+
+Prints ONE JSON line (rank 0).  `value` = steps of all ranks / max-over-ranks wall time of the timed
+region (barrier + device sync on both sides).  `roofline` prices the whole step against the fp64
+MFMA peak with the ALGORITHMIC flop count F_alg of SURVEY.md section 8d (never the padded/dense count);
+`cpu_baseline` times the oracle (reference algorithm as written, NumPy/LAPACK) on this box's cores.
+"""
+
+import argparse
+import json
+import os
+import pathlib
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT / "pnmol-experiments_amd"))
+
+import numpy as np  # noqa: E402
+
+PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X fp64 matrix peak (vendor figure)
+MESH_N, NU, DT = 512, 2, 2.0 ** -7
+
+
+def f_alg(D, m, n):
+    """Algorithmic flops of one covariance-form step."""
+    return m ** 3 / 3 + m ** 2 * D + D ** 2 * m + 4 * n * D ** 2 + 8 * (D * m + m ** 2)
+
+
+def build_problem(kappa, K):
+    import pnmol
+    pde = pnmol.pde.examples.heat_1d_discretized(
+        bbox=[0.0, 1.0], dx=1.0 / (MESH_N - 1), stencil_size_interior=3, stencil_size_boundary=3, t0=0.0,
+        tmax=K * DT, diffusion_rate=kappa, kernel=pnmol.kernels.SquareExponential(), nugget_gram_matrix_fd=0.0,
+        bcond="dirichlet")
+    solver = pnmol.white.LinearWhiteNoiseEK1(
+        num_derivatives=NU, steprule=pnmol.odetools.step.Constant(DT),
+        spatial_kernel=pnmol.kernels.Matern52() + pnmol.kernels.WhiteNoise())
+    return pde, solver
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """Oracle (reference algorithm as written: dense Nordsieck products + two QRs per step) on the same
+    workload, bounded sample."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import pnmol_oracle as o
+    pde = o.heat_1d_discretized(bbox=[0.0, 1.0], dx=1.0 / (MESH_N - 1), tmax=100 * DT, diffusion_rate=0.05,
+                                kernel=o.SquareExponential(), bcond="dirichlet")
+    s = o.WhiteNoiseEK1(num_derivatives=NU, steprule=o.Constant(DT), spatial_kernel=o.Matern52() + o.WhiteNoise())
+    state = s.initialize(pde)
+    state, _ = s.attempt_step(state, DT, pde)          # warm-up (BLAS threads, caches)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        state, _ = s.attempt_step(state, DT, pde)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget or n >= 100:
+            break
+    return {"value": n / el, "unit": "steps/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{n} steps of the N={MESH_N}, nu={NU} workload after 1 warm-up step; NumPy/SciPy "
+                      f"(LAPACK, threaded BLAS on all host cores), square-root form as written"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    os.environ["PNMOL_HIP_DEVICE"] = str(local_rank)
+
+    from pnmol import _hip
+    kappa = 0.05 if world == 1 else 0.01 * 10.0 ** (rank / 7.0)
+    pde, solver = build_problem(kappa, args.steps + args.warmup)
+    state = solver.initialize(pde)
+    flt, dev = solver._device_filter, state.y.device_state
+    solver._ensure_error_model(pde, DT)
+    ctx = _hip.Context.default()
+
+    def sync_all():
+        ctx.synchronize()
+        if dist is not None:
+            import torch
+            dist.barrier(device_ids=[local_rank])
+            torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        flt.steps(dev, args.warmup, DT, want_means=False, want_stds=False)
+    flt.prepare_steps(dev, args.steps, DT)   # one-off host work (buffers, hipGraph instantiation)
+    sync_all()
+    t0 = time.perf_counter()
+    means, stds, infos = flt.steps(dev, args.steps, DT)     # K steps, one host sync at the end
+    sync_all()
+    wall = time.perf_counter() - t0
+    dev_ms = flt.last_steps_ms()                              # HIP events on the ctx stream
+
+    sig = np.array([o.diffusion_squared_local for o in infos])
+    ok = bool(np.all(np.isfinite(means)) and np.all(np.isfinite(stds)) and all(o.info == -1 for o in infos))
+    if dist is not None:
+        import torch
+        tmax = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        wall = float(tmax.item())
+        # the final gather of the per-problem read-outs (the only collective of the path)
+        payload = torch.from_numpy(np.concatenate([means.ravel(), stds.ravel(), sig])).cuda()
+        gathered = [torch.empty_like(payload) for _ in range(world)]
+        dist.all_gather(gathered, payload)
+        ok_t = torch.tensor([1.0 if ok else 0.0], device="cuda")
+        dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+        ok = bool(ok_t.item() > 0.5)
+
+    if rank == 0:
+        n, d = NU + 1, MESH_N
+        D, m = n * d, d + 2
+        steps_per_s = world * args.steps / wall
+        flops = f_alg(D, m, n)
+        step_ms_dev = dev_ms / args.steps
+        achieved = flops / (step_ms_dev * 1e-3) / 1e12
+        line = {
+            "metric": "filter steps/sec, 1D heat N=512 nu=2 (white-noise EK1 predict+update)",
+            "value": steps_per_s, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"1-D heat equation, N={MESH_N} mesh, IWP(nu={NU}) EK1, Dirichlet, dt=2^-7, "
+                                   f"one problem per GPU (kappa sweep), D={D}, m={m}",
+                       "steps_in_one_call": args.steps, "valid": ok,
+                       "device_ms_per_step": step_ms_dev},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                         "note": "whole step (all kernels of one predict+update), F_alg = %.4g flop/step, "
+                                 "duration = HIP events on the launch stream / steps" % flops},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

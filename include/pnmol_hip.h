@@ -100,6 +100,10 @@ int pnmol_filter_step(pnmol_filter* f, const pnmol_state* in, double dt, pnmol_s
 int pnmol_filter_steps(pnmol_filter* f, pnmol_state* s, int k, double dt, double* means_kd,
                        double* stds_kd, pnmol_step_out* info_k);
 
+/* Optional: do the one-off host work of a following `pnmol_filter_steps(f, s, k, dt, ...)` now
+ * (output buffers, capture + instantiation of the hipGraphs the step loop is replayed from). */
+int pnmol_filter_prepare_steps(pnmol_filter* f, pnmol_state* s, int k, double dt);
+
 /* timing hooks for bench.py: HIP events on the ctx stream around the last `steps` call */
 int pnmol_filter_last_steps_ms(pnmol_filter* f, float* ms);
 

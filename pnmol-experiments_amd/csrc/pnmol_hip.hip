@@ -21,8 +21,10 @@
 //                (base/iwp.py:32-53) -> n x n block transform per (j,k) pair.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -123,9 +125,12 @@ __global__ __launch_bounds__(256) void k_pht(const double* __restrict__ Ppred, d
 }
 
 // z = H m- + shift, into the extra row block of G and into zbuf
+// Also advances the step counter: every later kernel of this step writes its per-step outputs to slot
+// *ctr - 1, so all steps launch with identical arguments and a captured hipGraph can be replayed.
 __global__ void k_zrow(const double* __restrict__ mpred, const double* __restrict__ shift, double* __restrict__ G,
-                       double* __restrict__ zbuf, MeasModel mm, long Dp) {
+                       double* __restrict__ zbuf, MeasModel mm, long Dp, int* __restrict__ ctr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *ctr += 1;
     if (i >= mm.mp) return;
     double v = 0.0;
     if (i < mm.m) {
@@ -140,12 +145,18 @@ __global__ void k_zrow(const double* __restrict__ mpred, const double* __restric
     zbuf[i] = v;
 }
 
-// G[ip, i] = S[ip, i] = (H (P- H^T))[ip, i] + R[ip, i];  identity on the padding
+// G[ip, i] = S[ip, i] = (H (P- H^T))[ip, i] + R[ip, i];  identity on the padding.
+// Rows ip >= mp (grid y = 2*mp) re-initialise the trailing identity block of G, which the sweep
+// turns into Ls^-T (rows of the tall matrix transform as row * Ls^-T).
 __global__ __launch_bounds__(256) void k_sbuild(double* __restrict__ G, const double* __restrict__ rdiag,
-                                                const double* __restrict__ Rdense, MeasModel mm) {
+                                                const double* __restrict__ Rdense, MeasModel mm, long rowI0) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int ip = blockIdx.y;
     if (i >= mm.mp) return;
+    if (ip >= mm.mp) {
+        G[(rowI0 + ip - mm.mp) * mm.mp + i] = (ip - mm.mp == i) ? 1.0 : 0.0;
+        return;
+    }
     double v;
     if (ip < mm.m && i < mm.m) {
         v = 0.0;
@@ -163,47 +174,79 @@ __global__ __launch_bounds__(256) void k_sbuild(double* __restrict__ G, const do
 }
 
 // ------------------------------------------------------------------------------------------
-// 32x32 Cholesky + triangular inverse of an LDS tile by one 256-thread workgroup.
-// In: T symmetric (lower read).  Out: T = L (upper zeroed), X = L^-1 (lower).
+// 32x32 Cholesky + triangular inverse by ONE wave, all data in registers.
+// Lane i < 32 holds row i of the symmetric tile in v[0..31]; lane 32+c starts from e_c.  Column step j:
+// every lane scales v[j] by 1/sqrt(pivot) and subtracts v[j] * l_kj from v[k], k > j, with l_kj
+// broadcast from lane k (v_readlane).  On lanes 0..31 that is right-looking Cholesky (v[k] = L[i][k]);
+// on lanes 32..63 the same instruction stream applies the elementary inverses E_j^-1 to the identity, so
+// lane 32+c ends with column c of L^-1 (v[r] = Linv[r][c]).  No LDS, no barriers.
 // ------------------------------------------------------------------------------------------
-__device__ void potrf32_inv(double* T, double* X, double* rs, int tid, int* info, int base) {
-    const int i = tid >> 3, kq = tid & 7;
+__device__ __forceinline__ double bcast_lane(double x, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double rsqrt_nr(double p) {
+    double y = __builtin_amdgcn_rsq(p);
+    double e = fma(-p * y, y, 1.0);
+    y = fma(0.5 * y, e, y);
+    e = fma(-p * y, y, 1.0);
+    return fma(0.5 * y, e, y);
+}
+
+//
+// Semi-definite handling: a pivot that has lost all significance against its original diagonal entry
+// S_jj (p <= 1e-13 |S_jj|) is treated as zero -- column j of L and row/column j of L^-1 become 0, i.e. that
+// measurement contributes nothing.  This is the noise-free Dirichlet row whose prior variance is already 0
+// (exact value 0, rounding noise of either sign in covariance form; the reference's square-root form gets
+// a tiny positive number and an equally negligible update).  Only a pivot that is negative at the 1e-3 level
+// of a significant row (or NaN) is reported through `info`.
+__device__ __forceinline__ void potrf32_inv_wave(double (&v)[NB], int lane, int* info, int base,
+                                                 double sdv /* lane q<32: |S_qq| of this block */, double smax) {
+    int bad = 0x7fffffff;
+#pragma unroll
     for (int j = 0; j < NB; ++j) {
-        __syncthreads();
-        const double p = T[j * TLD + j];
-        if (i > j) {
-            const double f = T[i * TLD + j] / p;
+        // branch-free column step (one basic block): uniform branches here let LLVM sink the updates of
+        // earlier columns down to their first use, which serialises them and spills SGPRs.
+        const double p = bcast_lane(v[j], j);
+        const double s0 = bcast_lane(sdv, j);
+        const bool ok = p > 1e-13 * s0;
+        const bool fatal = (!ok) & ((p != p) | ((p < -1e-3 * s0) & (s0 > 1e-12 * smax)));
+        bad = (fatal & (base + j < bad)) ? base + j : bad;
+        const double rs = rsqrt_nr(ok ? p : 1.0) * (ok ? 1.0 : 0.0);
+        const double vj = v[j] * rs;
+        v[j] = vj;
+        const double nvj = -vj;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int k = kq + 8 * q;
-                if (k > j && k <= i) T[i * TLD + k] -= f * T[k * TLD + j];
-            }
-        }
-    }
-    __syncthreads();
-    if (tid < NB) {
-        const double p = T[tid * TLD + tid];
-        if (!(p > 0.0)) atomicMin(info, base + tid);
-        rs[tid] = 1.0 / sqrt(p);
-    }
-    __syncthreads();
+        for (int k = j + 1; k < NB; ++k) v[k] = fma(nvj, bcast_lane(vj, k), v[k]);
+        // all updates of this column are complete here (register barrier, no instructions)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int k = kq + 8 * q;
-        T[i * TLD + k] = (k <= i) ? T[i * TLD + k] * rs[k] : 0.0;
-        X[i * TLD + k] = 0.0;
+        for (int k = j + 1; k < NB; ++k) asm volatile("" : "+v"(v[k]));
     }
-    __syncthreads();
-    const int c = tid >> 3;  // column of X owned by this 8-lane group
-    for (int r = 0; r < NB; ++r) {
-        double part = 0.0;
-        if (r >= c)
-            for (int k = c + kq; k < r; k += 8) part += T[r * TLD + k] * X[k * TLD + c];
-        part += __shfl_xor(part, 1);
-        part += __shfl_xor(part, 2);
-        part += __shfl_xor(part, 4);
-        if (kq == 0 && r >= c) X[r * TLD + c] = ((r == c ? 1.0 : 0.0) - part) * rs[r];
-        __syncthreads();
+    if (lane == 0 && bad != 0x7fffffff) atomicMin(info, bad);
+}
+
+// wave 0 of a workgroup factorises the LDS tile T (row stride TLD) and writes L (upper zeroed) to
+// Fd (leading dim ld) and L^-1 to Li (32x32 row-major)
+__device__ __forceinline__ void diag_from_lds(const double* T, double* __restrict__ Fd, long ld,
+                                              double* __restrict__ Li, int lane, int* info, int base,
+                                              const double* __restrict__ sdiag, double smax) {
+    double v[NB];
+    const int q = lane & 31;
+    const double sdv = fabs(sdiag[base + q]);
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const double t = T[q * TLD + k];
+        v[k] = (lane < 32) ? t : (k == q ? 1.0 : 0.0);
+    }
+    potrf32_inv_wave(v, lane, info, base, sdv, smax);
+    if (lane < 32) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) Fd[(long)q * ld + k] = (k <= q) ? v[k] : 0.0;
+    } else {
+#pragma unroll
+        for (int r = 0; r < NB; ++r) Li[r * NB + q] = v[r];
     }
 }
 
@@ -215,19 +258,26 @@ __device__ __forceinline__ void tile_g2s(const double* __restrict__ g, long ld, 
     }
 }
 
-// first diagonal block: F[0,0] = chol(G[0,0]), Linv[0] = its inverse
-__global__ __launch_bounds__(256) void k_diag0(const double* __restrict__ G, double* __restrict__ F,
-                                               double* __restrict__ Linv, int ld, int* info) {
-    __shared__ double sT[NB * TLD], sX[NB * TLD], rs[NB];
-    const int tid = threadIdx.x;
-    tile_g2s(G, ld, sT, tid);
-    potrf32_inv(sT, sX, rs, tid, info, 0);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int e = tid + 256 * q, r = e >> 5, cc = e & 31;
-        F[(long)r * ld + cc] = sT[r * TLD + cc];
-        Linv[r * NB + cc] = sX[r * TLD + cc];
+// first diagonal block: F[0,0] = chol(G[0,0]), Linv[0] = its inverse   (one wave)
+__global__ __launch_bounds__(64) void k_diag0(const double* __restrict__ G, double* __restrict__ F,
+                                              double* __restrict__ Linv, int ld, int* info_base,
+                                              double* __restrict__ sdiag /* [mp] diag S, then [mp] = max */,
+                                              const int* __restrict__ ctr) {
+    __shared__ double sT[NB * TLD];
+    const int lane = threadIdx.x;
+    int* info = info_base + (*ctr - 1);
+    double smax = 0.0;
+    for (int e = lane; e < ld; e += 64) {
+        const double x = G[(long)e * ld + e];
+        sdiag[e] = x;
+        smax = fmax(smax, fabs(x));
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) smax = fmax(smax, __shfl_xor(smax, o));
+    if (lane == 0) sdiag[ld] = smax;
+    for (int e = lane; e < NB * NB; e += 64) sT[(e >> 5) * TLD + (e & 31)] = G[(long)(e >> 5) * ld + (e & 31)];
+    __syncthreads();
+    diag_from_lds(sT, F, ld, Linv, lane, info, 0, sdiag, smax);
 }
 
 // panel j:  L_Ij = G_Ij Linv_j^T  for all row blocks I > j  (written to F by the c == 0 column),
@@ -235,8 +285,9 @@ __global__ __launch_bounds__(256) void k_diag0(const double* __restrict__ G, dou
 //           and the workgroup owning (j+1, j+1) factorises it for the next panel.
 __global__ __launch_bounds__(256) void k_panel(double* __restrict__ G, double* __restrict__ F,
                                                double* __restrict__ Linv, int ld, int j, int CB, int RBS,
-                                               int* info) {
-    __shared__ double sA[NB * TLD], sB[NB * TLD], sI[NB * TLD], rs[NB];
+                                               int* info_base, const double* __restrict__ sdiag,
+                                               const int* __restrict__ ctr) {
+    __shared__ double sA[NB * TLD], sB[NB * TLD], sI[NB * TLD];
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
     const int I = j + 1 + blockIdx.x;
     const int c = blockIdx.y;
@@ -282,24 +333,58 @@ __global__ __launch_bounds__(256) void k_panel(double* __restrict__ G, double* _
         for (int r = 0; r < 4; ++r) gt[(long)(wr * 16 + fk + 4 * r) * ld + wc * 16 + fr] = acc[r];
         return;
     }
-    // next diagonal block (j+1, j+1)
+    // next diagonal block (j+1, j+1): wave 0 factorises it for the next panel
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 4; ++r) sA[(wr * 16 + fk + 4 * r) * TLD + wc * 16 + fr] = acc[r];
-    potrf32_inv(sA, sB, rs, tid, info, (j + 1) * NB);
+    __syncthreads();
+    if (w == 0)
+        diag_from_lds(sA, F + ((long)(j + 1) * NB) * ld + (long)(j + 1) * NB, ld, Linv + (long)(j + 1) * NB * NB, l,
+                      info_base + (*ctr - 1), (j + 1) * NB, sdiag, sdiag[ld]);
+}
+
+// second reduction round + epilogue of k_downdate for wave WV in {0,1}
+template <int N, int WV>
+__device__ __forceinline__ void downdate_finish(d4 (&acc)[N][N], double* smem, const double* __restrict__ Ppred,
+                                                double* __restrict__ Pout, double* __restrict__ var, int dp, long Dp,
+                                                int J, int K, int l) {
+    constexpr int RED = N * N * 4 * 64;
+    const int fr = l & 15, fk = l >> 4;
+    double* wr = smem + (1 - WV) * RED;  // my contribution to the OTHER wave's registers
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int e = tid + 256 * q, r = e >> 5, cc = e & 31;
-        F[((long)(j + 1) * NB + r) * ld + (long)(j + 1) * NB + cc] = sA[r * TLD + cc];
-        Linv[(long)(j + 1) * NB * NB + r * NB + cc] = sB[r * TLD + cc];
-    }
+    for (int a = 0; a < N; ++a)
+#pragma unroll
+        for (int b = 0; b < N; ++b)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) wr[((a * N + b) * 2 + q) * 64 + l] = acc[a][b][(1 - WV) * 2 + q];
+    __syncthreads();
+    const double* rdo = smem + WV * RED;
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+#pragma unroll
+        for (int b = 0; b < N; ++b)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int r = WV * 2 + q;
+                const double sacc = acc[a][b][WV * 2 + q] + rdo[((a * N + b) * 2 + q) * 64 + l];
+                const int row = fk + 4 * r, col = fr;
+                const long gi = ((long)a * dp + J * 16 + row) * Dp + (long)b * dp + K * 16 + col;
+                const double x = Ppred[gi] - sacc;
+                Pout[gi] = x;
+                if (J != K) Pout[((long)b * dp + K * 16 + col) * Dp + (long)a * dp + J * 16 + row] = x;
+                if (J == K && a == b && row == col) var[a * dp + J * 16 + row] = x;
+            }
 }
 
 // ------------------------------------------------------------------------------------------
 // covariance down-date  P = P- - W W^T  on 16x16 point tiles x all n*n derivative blocks.
-// One workgroup (4 waves) per lower tile pair (J >= K); the waves split the inner (measurement)
-// dimension in 16-column chunks, partial sums are combined through LDS, wave 0 writes the tile
-// and its mirror image.  W = F + mp*ld  (Dp x mp).
+// One workgroup (4 waves) per lower tile pair (J >= K).  The waves split the inner (measurement)
+// dimension in interleaved 16-column chunks; each wave streams its chunks global -> registers (prefetch of
+// the next chunk) -> wave-private LDS -> MFMA fragments, with no workgroup barrier inside the loop.
+// Partial sums are combined through LDS in two rounds; waves 0/1 write the tile and its mirror image.
+// W = F + mp*ld  (Dp x mp).
 // ------------------------------------------------------------------------------------------
 template <int N>
 __global__ __launch_bounds__(256) void k_downdate(const double* __restrict__ Ppred, const double* __restrict__ W,
@@ -308,7 +393,7 @@ __global__ __launch_bounds__(256) void k_downdate(const double* __restrict__ Ppr
     constexpr int SLD = 17;                      // staging leading dim (16 cols + pad)
     constexpr int STG = 2 * N * 16 * SLD;        // doubles per wave staging
     constexpr int RED = N * N * 4 * 64;          // doubles per wave of partial sums
-    constexpr int LDS_D = (4 * STG > 3 * RED) ? 4 * STG : 3 * RED;
+    constexpr int LDS_D = (4 * STG > 2 * RED) ? 4 * STG : 2 * RED;
     __shared__ double smem[LDS_D];
     const int J = blockIdx.y, K = blockIdx.x;
     if (K > J) return;
@@ -324,47 +409,66 @@ __global__ __launch_bounds__(256) void k_downdate(const double* __restrict__ Ppr
 #pragma unroll
         for (int b = 0; b < N; ++b) acc[a][b] = (d4){0, 0, 0, 0};
 
+    const double* wa = W + ((long)J * 16 + lr) * mp + lc;
+    const double* wb = W + ((long)K * 16 + lr) * mp + lc;
+    const long hstride = 8L * mp, astride = (long)dp * mp;
+    double2 pa[N][2], pb[N][2];
     const int nchunks = mp / 16;
-    const int niter = (nchunks + 3) / 4;
-    for (int it = 0; it < niter; ++it) {
-        const int chunk = it * 4 + w;
-        __syncthreads();
-        if (chunk < nchunks) {
-            const int i0 = chunk * 16;
+    int chunk = w;
+    if (chunk < nchunks) {
+#pragma unroll
+        for (int a = 0; a < N; ++a)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                pa[a][h] = *reinterpret_cast<const double2*>(wa + a * astride + h * hstride + chunk * 16);
+                pb[a][h] = *reinterpret_cast<const double2*>(wb + a * astride + h * hstride + chunk * 16);
+            }
+    }
+    for (; chunk < nchunks; chunk += 4) {
+        // registers -> wave-private LDS (the previous chunk's fragment reads are older in this wave's LDS queue)
+#pragma unroll
+        for (int a = 0; a < N; ++a)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int r = lr + 8 * h;
+                st[(a * 16 + r) * SLD + lc] = pa[a][h].x;
+                st[(a * 16 + r) * SLD + lc + 1] = pa[a][h].y;
+                st[((N + a) * 16 + r) * SLD + lc] = pb[a][h].x;
+                st[((N + a) * 16 + r) * SLD + lc + 1] = pb[a][h].y;
+            }
+        const int nxt = chunk + 4;
+        if (nxt < nchunks) {
 #pragma unroll
             for (int a = 0; a < N; ++a)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const int r = lr + 8 * h;
-                    const double2 va = *reinterpret_cast<const double2*>(W + ((long)a * dp + J * 16 + r) * mp + i0 + lc);
-                    const double2 vb = *reinterpret_cast<const double2*>(W + ((long)a * dp + K * 16 + r) * mp + i0 + lc);
-                    st[(a * 16 + r) * SLD + lc] = va.x;
-                    st[(a * 16 + r) * SLD + lc + 1] = va.y;
-                    st[((N + a) * 16 + r) * SLD + lc] = vb.x;
-                    st[((N + a) * 16 + r) * SLD + lc + 1] = vb.y;
+                    pa[a][h] = *reinterpret_cast<const double2*>(wa + a * astride + h * hstride + nxt * 16);
+                    pb[a][h] = *reinterpret_cast<const double2*>(wb + a * astride + h * hstride + nxt * 16);
                 }
         }
-        __syncthreads();
-        if (chunk < nchunks) {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                double fa[N], fb[N];
+        for (int kk = 0; kk < 4; ++kk) {
+            double fa[N], fb[N];
 #pragma unroll
-                for (int a = 0; a < N; ++a) {
-                    fa[a] = st[(a * 16 + fr) * SLD + kk * 4 + fk];
-                    fb[a] = st[((N + a) * 16 + fr) * SLD + kk * 4 + fk];
-                }
-#pragma unroll
-                for (int a = 0; a < N; ++a)
-#pragma unroll
-                    for (int b = 0; b < N; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+            for (int a = 0; a < N; ++a) {
+                fa[a] = st[(a * 16 + fr) * SLD + kk * 4 + fk];
+                fb[a] = st[((N + a) * 16 + fr) * SLD + kk * 4 + fk];
             }
+#pragma unroll
+            for (int a = 0; a < N; ++a)
+#pragma unroll
+                for (int b = 0; b < N; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
         }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
     }
+    // round 1: waves 2,3 -> LDS, waves 0,1 accumulate
     __syncthreads();
-    if (w > 0) {
-        double* rd = smem + (w - 1) * RED;
+    if (w >= 2) {
+        double* rd = smem + (w - 2) * RED;
 #pragma unroll
         for (int a = 0; a < N; ++a)
 #pragma unroll
@@ -373,118 +477,94 @@ __global__ __launch_bounds__(256) void k_downdate(const double* __restrict__ Ppr
                 for (int r = 0; r < 4; ++r) rd[((a * N + b) * 4 + r) * 64 + l] = acc[a][b][r];
     }
     __syncthreads();
-    if (w != 0) return;
+    if (w >= 2) return;
+    {
+        const double* rd = smem + w * RED;
 #pragma unroll
-    for (int a = 0; a < N; ++a)
+        for (int a = 0; a < N; ++a)
 #pragma unroll
-        for (int b = 0; b < N; ++b)
+            for (int b = 0; b < N; ++b)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double s = acc[a][b][r];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) s += smem[q * RED + ((a * N + b) * 4 + r) * 64 + l];
-                const int row = fk + 4 * r, col = fr;
-                const long gi = ((long)a * dp + J * 16 + row) * Dp + (long)b * dp + K * 16 + col;
-                const double x = Ppred[gi] - s;
-                Pout[gi] = x;
-                if (J != K) Pout[((long)b * dp + K * 16 + col) * Dp + (long)a * dp + J * 16 + row] = x;
-                if (J == K && a == b && row == col) var[a * dp + J * 16 + row] = x;
-            }
+                for (int r = 0; r < 4; ++r) acc[a][b][r] += rd[((a * N + b) * 4 + r) * 64 + l];
+    }
+    // round 2 (waves 0,1 only; exited waves do not take part in the barrier): wave 0 finalises accumulator
+    // registers 0,1 and wave 1 registers 2,3 -- two instantiations so that every register index is static
+    __syncthreads();
+    if (w == 0)
+        downdate_finish<N, 0>(acc, smem, Ppred, Pout, var, dp, Dp, J, K, l);
+    else
+        downdate_finish<N, 1>(acc, smem, Ppred, Pout, var, dp, Dp, J, K, l);
 }
 
-// mean update  m = m- - W r   (one wave per state row)
-__global__ __launch_bounds__(256) void k_meanupd(const double* __restrict__ mpred, const double* __restrict__ W,
-                                                 const double* __restrict__ r, double* __restrict__ mout, int mp,
-                                                 long Dp) {
+// One wave per row of four matrix-vector products that all need the finished sweep:
+//   rows [0, Dp)          m = m- - W r                               (mean update, white.py:123)
+//   rows [Dp, Dp+mp)      part[0][i] = r_i^2                         (whitened residual)
+//                         part[1][i] = (Ls^-T z)_i^2                 (white.py:125 with the Cholesky factor)
+//                         part[2][i] = z_i (Sq^-1 z)_i               (estimate_error, white.py:153-162)
+__global__ __launch_bounds__(256) void k_vecops(const double* __restrict__ mpred, const double* __restrict__ W,
+                                                const double* __restrict__ r, const double* __restrict__ LinvT,
+                                                const double* __restrict__ z, const double* __restrict__ Sqinv,
+                                                double* __restrict__ mout, double* __restrict__ part, int mp,
+                                                long Dp) {
     const int l = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= Dp) return;
-    double s = 0.0;
-    for (int i = l; i < mp; i += 64) s += W[row * mp + i] * r[i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (l == 0) mout[row] = mpred[row] - s;
-}
-
-__device__ double block_sum(double v, double* sred) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    __syncthreads();
-    if (l == 0) sred[w] = v;
-    __syncthreads();
-    double t = 0.0;
-    for (int q = 0; q < (int)(blockDim.x >> 6); ++q) t += sred[q];
-    return t;
-}
-
-// rec[0] = |r|^2,  rec[2] = z^T Sqinv z   (single workgroup of 1024 threads)
-__global__ __launch_bounds__(1024) void k_stats(const double* __restrict__ r, const double* __restrict__ z,
-                                                const double* __restrict__ Sqinv, double* __restrict__ rec, int mp) {
-    __shared__ double sred[16];
-    double a = 0.0, e = 0.0;
-    for (int col = threadIdx.x; col < mp; col += blockDim.x) {
-        a += r[col] * r[col];
-        if (Sqinv) {
-            double y = 0.0;
-            for (int i = 0; i < mp; ++i) y += Sqinv[(long)i * mp + col] * z[i];
-            e += y * z[col];
-        }
-    }
-    a = block_sum(a, sred);
-    e = block_sum(e, sred);
-    if (threadIdx.x == 0) {
-        rec[0] = a;
-        rec[2] = Sqinv ? e : nan("");
-    }
-}
-
-// x = Ls^-T z by block back-substitution with the inverted diagonal blocks;  rec[1] = |x|^2.
-// This is the reference's `solve_triangular(Sl.T, z)` (white.py:125) with the Cholesky factor.
-__global__ __launch_bounds__(256) void k_backsolve(const double* __restrict__ F, const double* __restrict__ Linv,
-                                                   const double* __restrict__ z, double* __restrict__ rec, int mp,
-                                                   int CB, double* __restrict__ xout) {
-    extern __shared__ double sx[];  // mp + 256 + 32
-    double* part = sx + mp;
-    double* tt = part + 256;
-    __shared__ double sred[4];
-    const int tid = threadIdx.x, c = tid & 31, g = tid >> 5;
-    for (int i = tid; i < mp; i += 256) sx[i] = z[i];
-    __syncthreads();
-    for (int jb = CB - 1; jb >= 0; --jb) {
+    if (row < Dp) {
         double s = 0.0;
-        for (int row = (jb + 1) * NB + g; row < mp; row += 8) s += F[(long)row * mp + jb * NB + c] * sx[row];
-        part[g * 32 + c] = s;
-        __syncthreads();
-        if (tid < 32) {
-            double t = sx[jb * NB + tid];
-            for (int q = 0; q < 8; ++q) t -= part[q * 32 + tid];
-            tt[tid] = t;
+        for (int i = l; i < mp; i += 64) s += W[row * mp + i] * r[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (l == 0) mout[row] = mpred[row] - s;
+    } else if (row < Dp + mp) {
+        const long q = row - Dp;
+        double x = 0.0, y = 0.0;
+        for (int i = l; i < mp; i += 64) {
+            const double zi = z[i];
+            x += LinvT[q * mp + i] * zi;
+            if (Sqinv) y += Sqinv[q * mp + i] * zi;
         }
-        __syncthreads();
-        if (tid < 32) {
-            double xv = 0.0;
-            for (int q = tid; q < 32; ++q) xv += Linv[(long)jb * NB * NB + q * NB + tid] * tt[q];
-            sx[jb * NB + tid] = xv;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            x += __shfl_xor(x, o);
+            y += __shfl_xor(y, o);
         }
-        __syncthreads();
+        if (l == 0) {
+            part[q] = r[q] * r[q];
+            part[mp + q] = x * x;
+            part[2 * mp + q] = z[q] * y;
+        }
     }
-    double a = 0.0;
-    for (int i = tid; i < mp; i += 256) {
-        a += sx[i] * sx[i];
-        if (xout) xout[i] = sx[i];
-    }
-    a = block_sum(a, sred);
-    if (tid == 0) rec[1] = a;
 }
 
-// per-step read-out of the parity quantities (experiments/figure1.py:76-80), raw coordinates
-__global__ void k_readout(const double* __restrict__ mean, const double* __restrict__ var, double* __restrict__ means,
-                          double* __restrict__ stds, double s0, int d) {
+// per-step read-out of the parity quantities (experiments/figure1.py:76-80), raw coordinates;
+// block 0 also reduces the partial sums of k_vecops into rec[0..2] (fixed order: deterministic)
+__global__ __launch_bounds__(256) void k_readout(const double* __restrict__ mean, const double* __restrict__ var,
+                                                 double* __restrict__ means_base, double* __restrict__ stds_base,
+                                                 double s0, int d, const double* __restrict__ part,
+                                                 double* __restrict__ rec_base, int mp, const int* __restrict__ ctr) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= d) return;
-    if (means) means[j] = s0 * mean[j];
-    if (stds) stds[j] = s0 * sqrt(fmax(var[j], 0.0));
+    const int slot = *ctr - 1;
+    double* means = means_base ? means_base + (size_t)slot * d : nullptr;
+    double* stds = stds_base ? stds_base + (size_t)slot * d : nullptr;
+    double* rec = rec_base + 4 * (size_t)slot;
+    if (j < d) {
+        if (means) means[j] = s0 * mean[j];
+        if (stds) stds[j] = s0 * sqrt(fmax(var[j], 0.0));
+    }
+    if (blockIdx.x == 0) {
+        __shared__ double sred[3][4];
+        double a[3] = {0.0, 0.0, 0.0};
+        for (int i = threadIdx.x; i < mp; i += 256)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) a[q] += part[q * mp + i];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) a[q] += __shfl_xor(a[q], o);
+        if ((threadIdx.x & 63) == 0)
+            for (int q = 0; q < 3; ++q) sred[q][threadIdx.x >> 6] = a[q];
+        __syncthreads();
+        if (threadIdx.x < 3) rec[threadIdx.x] = sred[threadIdx.x][0] + sred[threadIdx.x][1] + sred[threadIdx.x][2] + sred[threadIdx.x][3];
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -524,16 +604,28 @@ struct pnmol_filter {
     double* ell_val = nullptr;
     double *Kg = nullptr, *rdiag = nullptr, *Rdense = nullptr, *shift = nullptr;
     double *G = nullptr, *F = nullptr, *Linv = nullptr, *Ppred = nullptr, *mpred = nullptr, *zbuf = nullptr;
-    double *var = nullptr, *Sqinv = nullptr, *rec = nullptr, *xbuf = nullptr;
+    double *var = nullptr, *Sqinv = nullptr, *rec = nullptr, *part = nullptr, *sdiag = nullptr;
     int* info = nullptr;
     std::vector<double> sqdiag;
     double sq_dt = -1.0;
     // scratch state for ping-pong inside steps()
     double *tmpP = nullptr, *tmpMean = nullptr;
     double *rec_means = nullptr, *rec_stds = nullptr;
+    double* h_pin = nullptr;  // pinned host staging: [rec 4k | means k*d | stds k*d | info k ints]
     int rec_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.f;
+    int* ctr = nullptr;  // device step counter (slot of the per-step outputs)
+    struct GraphEntry {
+        double *P0, *P1, *var;
+        double dt;
+        int nsteps;
+        bool have_sq;
+        hipGraphExec_t exec;
+        bool launched;  // the first launch of an executable graph costs ~50 ms of host time (ROCm 7.2)
+    };
+    std::vector<GraphEntry> graphs;
+    int graph_chunk = 10;  // steps per captured graph (even); 0 disables graphs
 };
 
 struct pnmol_state {
@@ -547,9 +639,11 @@ struct pnmol_state {
 
 namespace {
 
+void drop_graphs(pnmol_filter* f);
+
 template <int N>
 int launch_step(pnmol_filter* f, const double* Pin, const double* min, double frame_dt, double dt, double* Pout,
-                double* mout, double* varout, int step_slot, double* means_out, double* stds_out) {
+                double* mout, double* varout, bool record) {
     pnmol_ctx* ctx = f->ctx;
     hipStream_t st = ctx->stream;
     IwpConsts c = f->iwp;
@@ -561,30 +655,29 @@ int launch_step(pnmol_filter* f, const double* Pin, const double* min, double fr
                  nordsieck_scale(f->nu, 0, dt), nordsieck_scale(f->nu, 1, dt)};
     const int dp = f->dp, mp = f->mp;
     const long Dp = f->Dp;
-    double* rec = f->rec + 4L * step_slot;
-    int* info = f->info + step_slot;
 
     k_predict<N><<<dim3(dp / 32, dp / 8), dim3(32, 8), 0, st>>>(Pin, f->Ppred, f->Kg, c, dp);
     k_predict_mean<N><<<(dp + 255) / 256, 256, 0, st>>>(min, f->mpred, c, dp);
     k_pht<<<dim3((mp + 255) / 256, (unsigned)Dp), 256, 0, st>>>(f->Ppred, f->G, mm, Dp);
-    k_zrow<<<(mp + 255) / 256, 256, 0, st>>>(f->mpred, f->shift, f->G, f->zbuf, mm, Dp);
-    k_sbuild<<<dim3((mp + 255) / 256, mp), 256, 0, st>>>(f->G, f->rdiag, f->Rdense, mm);
-    k_diag0<<<1, 256, 0, st>>>(f->G, f->F, f->Linv, mp, info);
+    k_zrow<<<(mp + 255) / 256, 256, 0, st>>>(f->mpred, f->shift, f->G, f->zbuf, mm, Dp, f->ctr);
+    const long rowI0 = (long)mp + Dp + NB;
+    k_sbuild<<<dim3((mp + 255) / 256, 2 * mp), 256, 0, st>>>(f->G, f->rdiag, f->Rdense, mm, rowI0);
+    k_diag0<<<1, 64, 0, st>>>(f->G, f->F, f->Linv, mp, f->info, f->sdiag, f->ctr);
     for (int j = 0; j < f->CB; ++j) {
         const int nrb = f->RT - (j + 1);
         const int ncb = f->CB - 1 - j > 0 ? f->CB - 1 - j : 1;
-        k_panel<<<dim3(nrb, ncb), 256, 0, st>>>(f->G, f->F, f->Linv, mp, j, f->CB, f->RBS, info);
+        k_panel<<<dim3(nrb, ncb), 256, 0, st>>>(f->G, f->F, f->Linv, mp, j, f->CB, f->RBS, f->info, f->sdiag, f->ctr);
     }
     const double* W = f->F + (long)mp * mp;
     const double* r = f->F + ((long)mp + Dp) * mp;
+    const double* LinvT = f->F + rowI0 * mp;
     const bool have_sq = (f->Sqinv != nullptr && f->sq_dt == dt);
-    k_stats<<<1, 1024, 0, st>>>(r, f->zbuf, have_sq ? f->Sqinv : nullptr, rec, mp);
-    k_backsolve<<<1, 256, (mp + 256 + 32) * sizeof(double), st>>>(f->F, f->Linv, f->zbuf, rec, mp, f->CB, f->xbuf);
-    k_meanupd<<<(unsigned)((Dp + 3) / 4), 256, 0, st>>>(f->mpred, W, r, mout, mp, Dp);
+    k_vecops<<<(unsigned)((Dp + mp + 3) / 4), 256, 0, st>>>(f->mpred, W, r, LinvT, f->zbuf, have_sq ? f->Sqinv : nullptr,
+                                                            mout, f->part, mp, Dp);
     k_downdate<N><<<dim3(dp / 16, dp / 16), 256, 0, st>>>(f->Ppred, W, Pout, varout, dp, mp);
-    if (means_out || stds_out)
-        k_readout<<<(f->d + 255) / 256, 256, 0, st>>>(mout, varout, means_out, stds_out,
-                                                      nordsieck_scale(f->nu, 0, dt), f->d);
+    k_readout<<<(f->d + 255) / 256, 256, 0, st>>>(mout, varout, record ? f->rec_means : nullptr,
+                                                  record ? f->rec_stds : nullptr, nordsieck_scale(f->nu, 0, dt), f->d,
+                                                  f->part, f->rec, mp, f->ctr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         ctx->err = std::string("kernel launch: ") + hipGetErrorString(e);
@@ -594,24 +687,85 @@ int launch_step(pnmol_filter* f, const double* Pin, const double* min, double fr
 }
 
 int dispatch_step(pnmol_filter* f, const double* Pin, const double* min, double frame_dt, double dt, double* Pout,
-                  double* mout, double* varout, int slot, double* mo, double* so) {
+                  double* mout, double* varout, bool record) {
     switch (f->n) {
-        case 2: return launch_step<2>(f, Pin, min, frame_dt, dt, Pout, mout, varout, slot, mo, so);
-        case 3: return launch_step<3>(f, Pin, min, frame_dt, dt, Pout, mout, varout, slot, mo, so);
-        case 4: return launch_step<4>(f, Pin, min, frame_dt, dt, Pout, mout, varout, slot, mo, so);
+        case 2: return launch_step<2>(f, Pin, min, frame_dt, dt, Pout, mout, varout, record);
+        case 3: return launch_step<3>(f, Pin, min, frame_dt, dt, Pout, mout, varout, record);
+        case 4: return launch_step<4>(f, Pin, min, frame_dt, dt, Pout, mout, varout, record);
     }
     return -1;
 }
 
+void drop_graphs(pnmol_filter* f) {
+    for (auto& g : f->graphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    f->graphs.clear();
+}
+
+// A captured run of `nsteps` (even) constant-dt steps that ping-pongs P0 -> P1 -> P0 ...; all per-step
+// outputs are addressed through the device step counter, so one executable graph serves any position of
+// the sequence.
+int get_graph(pnmol_filter* f, double* P0, double* M0, double* P1, double* M1, double* var, double dt, int nsteps,
+              hipGraphExec_t* out) {
+    pnmol_ctx* ctx = f->ctx;
+    const bool have_sq = (f->Sqinv != nullptr && f->sq_dt == dt);
+    for (auto& g : f->graphs)
+        if (g.P0 == P0 && g.P1 == P1 && g.var == var && g.dt == dt && g.nsteps == nsteps && g.have_sq == have_sq) {
+            *out = g.exec;
+            return 0;
+        }
+    if (f->graphs.size() >= 8) drop_graphs(f);
+    hipGraph_t graph = nullptr;
+    HIPCHK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    int rc = 0;
+    for (int it = 0; it < nsteps && rc == 0; ++it)
+        rc = (it & 1) ? dispatch_step(f, P1, M1, dt, dt, P0, M0, var, true)
+                      : dispatch_step(f, P0, M0, dt, dt, P1, M1, var, true);
+    hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+    if (rc != 0 || e != hipSuccess) {
+        if (graph) (void)hipGraphDestroy(graph);
+        if (rc == 0) ctx->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e);
+        return rc != 0 ? rc : -2;
+    }
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) {
+        ctx->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e);
+        return -2;
+    }
+    f->graphs.push_back({P0, P1, var, dt, nsteps, have_sq, exec, false});
+    *out = exec;
+    return 0;
+}
+
+// graphs for `k` constant-dt steps from state `s` (host work: capture + instantiate, cached)
+int prepare_graphs(pnmol_filter* f, pnmol_state* s, int k, double dt, hipGraphExec_t* gbig, hipGraphExec_t* gpair) {
+    *gbig = *gpair = nullptr;
+    if (f->graph_chunk < 2) return 0;
+    double *curP = s->P, *curM = s->mean, *nxtP = f->tmpP, *nxtM = f->tmpMean;
+    const int lead = (s->frame_dt != dt) ? 1 : 0;  // a frame change has its own constants: that step runs eagerly
+    const int rest = k - lead;
+    double *gP0 = lead ? nxtP : curP, *gM0 = lead ? nxtM : curM, *gP1 = lead ? curP : nxtP, *gM1 = lead ? curM : nxtM;
+    int rc = 0;
+    if (rest >= f->graph_chunk) rc = get_graph(f, gP0, gM0, gP1, gM1, s->var, dt, f->graph_chunk, gbig);
+    if (rc == 0 && (rest % f->graph_chunk) >= 2) rc = get_graph(f, gP0, gM0, gP1, gM1, s->var, dt, 2, gpair);
+    return rc;
+}
+
 int ensure_rec(pnmol_filter* f, int k) {
     if (k <= f->rec_cap) return 0;
+    if (k < 128) k = 128;
     pnmol_ctx* ctx = f->ctx;
+    drop_graphs(f);  // rec/info/read-out pointers are baked into captured graphs
     if (f->rec) hipFree(f->rec);
     if (f->info) hipFree(f->info);
     if (f->rec_means) hipFree(f->rec_means);
     if (f->rec_stds) hipFree(f->rec_stds);
-    f->rec = nullptr, f->info = nullptr, f->rec_means = nullptr, f->rec_stds = nullptr;
+    if (f->h_pin) hipHostFree(f->h_pin);
+    f->rec = nullptr, f->info = nullptr, f->rec_means = nullptr, f->rec_stds = nullptr, f->h_pin = nullptr;
     f->rec_cap = 0;
+    HIPCHK(ctx, hipHostMalloc(&f->h_pin, sizeof(double) * ((size_t)4 * k + 2 * (size_t)k * f->d + (size_t)k), 0));
     HIPCHK(ctx, hipMalloc(&f->rec, sizeof(double) * 4 * k));
     HIPCHK(ctx, hipMalloc(&f->info, sizeof(int) * k));
     HIPCHK(ctx, hipMalloc(&f->rec_means, sizeof(double) * (size_t)k * f->d));
@@ -692,7 +846,7 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
     f->d = d, f->nu = nu, f->n = n, f->nB = nB, f->m = d + nB;
     f->dp = round_up(d, NB), f->mp = round_up(f->m, NB);
     f->Dp = (long)n * f->dp;
-    f->CB = f->mp / NB, f->RBS = f->mp / NB, f->RBW = (int)(f->Dp / NB), f->RT = f->RBS + f->RBW + 1;
+    f->CB = f->mp / NB, f->RBS = f->mp / NB, f->RBW = (int)(f->Dp / NB), f->RT = f->RBS + f->RBW + 1 + f->RBS;  // [S; W; z-block; I]
     const int dp = f->dp, mp = f->mp, m = f->m;
     const long Dp = f->Dp;
 
@@ -800,7 +954,10 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
     FCHK(hipMalloc(&f->tmpMean, sizeof(double) * Dp));
     FCHK(hipMalloc(&f->var, sizeof(double) * Dp));
     FCHK(hipMalloc(&f->zbuf, sizeof(double) * mp));
-    FCHK(hipMalloc(&f->xbuf, sizeof(double) * mp));
+    FCHK(hipMalloc(&f->part, sizeof(double) * 3 * mp));
+    FCHK(hipMalloc(&f->ctr, sizeof(int)));
+    if (const char* gc = std::getenv("PNMOL_HIP_GRAPH_CHUNK")) f->graph_chunk = std::atoi(gc) / 2 * 2;
+    FCHK(hipMalloc(&f->sdiag, sizeof(double) * (mp + 1)));
     FCHK(hipMemcpy(f->ell_col, ecol.data(), sizeof(int) * ecol.size(), hipMemcpyHostToDevice));
     FCHK(hipMemcpy(f->ell_val, eval.data(), sizeof(double) * eval.size(), hipMemcpyHostToDevice));
     FCHK(hipMemcpy(f->Kg, Kg.data(), sizeof(double) * Kg.size(), hipMemcpyHostToDevice));
@@ -818,7 +975,7 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
     FCHK(hipEventCreate(&f->ev0));
     FCHK(hipEventCreate(&f->ev1));
 #undef FCHK
-    if (ensure_rec(f, 1) != 0) return fail(-2);
+    if (ensure_rec(f, 128) != 0) return fail(-2);
     *out = f;
     return 0;
 }
@@ -826,8 +983,11 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
 int pnmol_filter_destroy(pnmol_filter* f) {
     if (!f) return -1;
     hipSetDevice(f->ctx->device);
+    drop_graphs(f);
+    if (f->ctr) hipFree(f->ctr);
+    if (f->h_pin) hipHostFree(f->h_pin);
     void* ptrs[] = {f->ell_col, f->ell_val, f->Kg,   f->rdiag,   f->Rdense, f->shift,     f->G,        f->F,
-                    f->Linv,    f->Ppred,   f->mpred, f->zbuf,   f->var,    f->Sqinv,     f->rec,      f->xbuf,
+                    f->Linv,    f->Ppred,   f->mpred, f->zbuf,   f->var,    f->Sqinv,     f->rec,      f->part,  f->sdiag,
                     f->info,    f->tmpP,    f->tmpMean, f->rec_means, f->rec_stds};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -859,6 +1019,7 @@ int pnmol_filter_set_error_model(pnmol_filter* f, double dt, const double* Sq_in
     HIPCHK(ctx, hipMemcpy(f->Sqinv, pad.data(), sizeof(double) * pad.size(), hipMemcpyHostToDevice));
     f->sqdiag.assign(Sq_diag, Sq_diag + m);
     f->sq_dt = dt;
+    drop_graphs(f);
     return 0;
 }
 
@@ -1008,7 +1169,8 @@ int pnmol_filter_step(pnmol_filter* f, const pnmol_state* in, double dt, pnmol_s
     pnmol_ctx* ctx = f->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemsetAsync(f->info, 0x7f, sizeof(int), ctx->stream));
-    int rc = dispatch_step(f, in->P, in->mean, in->frame_dt, dt, out->P, out->mean, out->var, 0, nullptr, nullptr);
+    HIPCHK(ctx, hipMemsetAsync(f->ctr, 0, sizeof(int), ctx->stream));
+    int rc = dispatch_step(f, in->P, in->mean, in->frame_dt, dt, out->P, out->mean, out->var, false);
     if (rc != 0) return rc;
     double rec[4];
     int inf = 0;
@@ -1045,34 +1207,63 @@ int pnmol_filter_steps(pnmol_filter* f, pnmol_state* s, int k, double dt, double
     if (rc != 0) return rc;
     hipStream_t st = ctx->stream;
     HIPCHK(ctx, hipMemsetAsync(f->info, 0x7f, sizeof(int) * k, st));
-    HIPCHK(ctx, hipEventRecord(f->ev0, st));
+    HIPCHK(ctx, hipMemsetAsync(f->ctr, 0, sizeof(int), st));
     double *curP = s->P, *curM = s->mean, *nxtP = f->tmpP, *nxtM = f->tmpMean;
     double frame = s->frame_dt;
-    for (int it = 0; it < k; ++it) {
-        rc = dispatch_step(f, curP, curM, frame, dt, nxtP, nxtM, s->var, it, f->rec_means + (size_t)it * f->d,
-                           f->rec_stds + (size_t)it * f->d);
+    const bool trace = std::getenv("PNMOL_HIP_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tA = now();
+    hipGraphExec_t gbig = nullptr, gpair = nullptr;
+    rc = prepare_graphs(f, s, k, dt, &gbig, &gpair);
+    if (rc != 0) return rc;
+    const double tB = now();
+    HIPCHK(ctx, hipEventRecord(f->ev0, st));
+    int it = 0;
+    while (it < k) {
+        const int left = k - it;
+        if (frame == dt && gbig && left >= f->graph_chunk) {
+            HIPCHK(ctx, hipGraphLaunch(gbig, st));
+            for (auto& g : f->graphs) g.launched = g.launched || g.exec == gbig;
+            it += f->graph_chunk;  // even number of steps: buffers are back where they started
+            continue;
+        }
+        if (frame == dt && gpair && left >= 2) {
+            HIPCHK(ctx, hipGraphLaunch(gpair, st));
+            for (auto& g : f->graphs) g.launched = g.launched || g.exec == gpair;
+            it += 2;
+            continue;
+        }
+        rc = dispatch_step(f, curP, curM, frame, dt, nxtP, nxtM, s->var, true);
         if (rc != 0) return rc;
         double* t;
         t = curP, curP = nxtP, nxtP = t;
         t = curM, curM = nxtM, nxtM = t;
         frame = dt;
+        ++it;
     }
     HIPCHK(ctx, hipEventRecord(f->ev1, st));
+    const double tC = now();
     // the filter owns tmpP/tmpMean: after an odd number of steps the result lives there -> swap ownership
     if (curP != s->P) {
         f->tmpP = s->P, f->tmpMean = s->mean;
         s->P = curP, s->mean = curM;
     }
-    std::vector<double> rec((size_t)4 * k);
-    std::vector<int> inf(k);
-    HIPCHK(ctx, hipMemcpyAsync(rec.data(), f->rec, sizeof(double) * rec.size(), hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipMemcpyAsync(inf.data(), f->info, sizeof(int) * k, hipMemcpyDeviceToHost, st));
-    if (means_kd)
-        HIPCHK(ctx, hipMemcpyAsync(means_kd, f->rec_means, sizeof(double) * (size_t)k * f->d, hipMemcpyDeviceToHost, st));
-    if (stds_kd)
-        HIPCHK(ctx, hipMemcpyAsync(stds_kd, f->rec_stds, sizeof(double) * (size_t)k * f->d, hipMemcpyDeviceToHost, st));
+    // device -> pinned staging (allocated in ensure_rec) -> caller's buffers
+    double* rec = f->h_pin;
+    double* hm = rec + (size_t)4 * f->rec_cap;
+    double* hs = hm + (size_t)f->rec_cap * f->d;
+    int* inf = reinterpret_cast<int*>(hs + (size_t)f->rec_cap * f->d);
+    HIPCHK(ctx, hipMemcpyAsync(rec, f->rec, sizeof(double) * 4 * k, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(inf, f->info, sizeof(int) * k, hipMemcpyDeviceToHost, st));
+    if (means_kd) HIPCHK(ctx, hipMemcpyAsync(hm, f->rec_means, sizeof(double) * (size_t)k * f->d, hipMemcpyDeviceToHost, st));
+    if (stds_kd) HIPCHK(ctx, hipMemcpyAsync(hs, f->rec_stds, sizeof(double) * (size_t)k * f->d, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     HIPCHK(ctx, hipEventElapsedTime(&f->last_ms, f->ev0, f->ev1));
+    if (trace)
+        std::fprintf(stderr, "[pnmol] steps(k=%d): prepare %.2f ms, enqueue %.2f ms, wait+copy %.2f ms, device %.2f ms, graphs big=%d pair=%d\n",
+                     k, tB - tA, tC - tB, now() - tC, f->last_ms, gbig != nullptr, gpair != nullptr);
+    if (means_kd) std::memcpy(means_kd, hm, sizeof(double) * (size_t)k * f->d);
+    if (stds_kd) std::memcpy(stds_kd, hs, sizeof(double) * (size_t)k * f->d);
     const bool have_sq = (f->Sqinv != nullptr && f->sq_dt == dt);
     int bad = -1;
     double t = s->t;
@@ -1090,6 +1281,44 @@ int pnmol_filter_steps(pnmol_filter* f, pnmol_state* s, int k, double dt, double
         return -3;
     }
     return 0;
+}
+
+int pnmol_filter_prepare_steps(pnmol_filter* f, pnmol_state* s, int k, double dt) {
+    if (!f || !s || s->f != f || k < 1 || !(dt > 0.0)) return -1;
+    pnmol_ctx* ctx = f->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_rec(f, k);
+    if (rc != 0) return rc;
+    // Rehearse the exact launch sequence once on the live buffers and restore them: graph capture,
+    // instantiation and the runtime's first-launch work (tens of ms on ROCm 7.2) then happen here.
+    const size_t Dp = (size_t)f->Dp, nP = Dp * Dp;
+    double* bak = nullptr;
+    HIPCHK(ctx, hipMalloc(&bak, sizeof(double) * (nP + 2 * Dp)));
+    hipStream_t st = ctx->stream;
+    const double t0 = s->t, frame0 = s->frame_dt;
+    hipError_t e = hipMemcpyAsync(bak, s->P, sizeof(double) * nP, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(bak + nP, s->mean, sizeof(double) * Dp, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(bak + nP + Dp, s->var, sizeof(double) * Dp, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) {
+        rc = pnmol_filter_steps(f, s, k, dt, nullptr, nullptr, nullptr);
+        if (rc == -3) rc = 0;  // a non-PD rehearsal is reported by the real call
+        if ((k & 1) && rc == 0) {  // odd k swapped buffer ownership: swap back so the cached graphs stay valid
+            double* t;
+            t = s->P, s->P = f->tmpP, f->tmpP = t;
+            t = s->mean, s->mean = f->tmpMean, f->tmpMean = t;
+        }
+        e = hipMemcpyAsync(s->P, bak, sizeof(double) * nP, hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(s->mean, bak + nP, sizeof(double) * Dp, hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(s->var, bak + nP + Dp, sizeof(double) * Dp, hipMemcpyDeviceToDevice, st);
+        s->t = t0, s->frame_dt = frame0;
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(bak);
+    if (e != hipSuccess) {
+        ctx->err = std::string("pnmol_filter_prepare_steps: ") + hipGetErrorString(e);
+        return -2;
+    }
+    return rc;
 }
 
 int pnmol_filter_last_steps_ms(pnmol_filter* f, float* ms) {

@@ -64,6 +64,7 @@ SYMBOLS = {
     "pnmol_filter_step": (ctypes.c_int, [_vp, _vp, ctypes.c_double, _vp, ctypes.POINTER(StepOut), _c_double_p]),
     "pnmol_filter_steps": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_double, _c_double_p, _c_double_p,
                                           ctypes.POINTER(StepOut)]),
+    "pnmol_filter_prepare_steps": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_double]),
     "pnmol_filter_last_steps_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "pnmol_filter_debug_read": (ctypes.c_int, [_vp, ctypes.c_int, _c_double_p, ctypes.c_long]),
     "pnmol_filter_dims": (ctypes.c_int, [_vp] + [ctypes.POINTER(ctypes.c_int)] * 5),
@@ -190,6 +191,10 @@ class Filter:
                                          _dp(means) if want_means else None, _dp(stds) if want_stds else None, infos)
         self.ctx.check(rc, "pnmol_filter_steps")
         return means, stds, infos
+
+    def prepare_steps(self, state, k, dt):
+        self.ctx.check(self.lib.pnmol_filter_prepare_steps(self.handle, state.handle, int(k), float(dt)),
+                       "pnmol_filter_prepare_steps")
 
     def last_steps_ms(self):
         ms = ctypes.c_float(0.0)
