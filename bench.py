@@ -62,7 +62,12 @@ def cpu_baseline(seconds_budget=20.0):
         el = time.perf_counter() - t0
         if el > seconds_budget or n >= 100:
             break
-    return {"value": n / el, "unit": "steps/s", "cores": os.cpu_count(), "kind": "port",
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([t.get("num_threads", 1) for t in threadpool_info()] or [1])   # BLAS threads actually used
+    except Exception:
+        cores = os.cpu_count()
+    return {"value": n / el, "unit": "steps/s", "cores": cores, "kind": "port",
             "sample": f"{n} steps of the N={MESH_N}, nu={NU} workload after 1 warm-up step; NumPy/SciPy "
                       f"(LAPACK, threaded BLAS on all host cores), square-root form as written"}
 
@@ -82,12 +87,20 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        ndev = max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local_rank % ndev)
+        # "nccl" is RCCL on ROCm.  PNMOL_BENCH_BACKEND=gloo is only for rehearsing N>1 ranks on a 1-GPU box.
+        backend = os.environ.get("PNMOL_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank % ndev))
+        else:
+            dist.init_process_group(backend)
+    coll_dev = "cuda" if os.environ.get("PNMOL_BENCH_BACKEND", "nccl") == "nccl" else "cpu"
     os.environ["PNMOL_HIP_DEVICE"] = str(local_rank)
 
-    from pnmol import _hip
-    kappa = 0.05 if world == 1 else 0.01 * 10.0 ** (rank / 7.0)
+    from pnmol import _hip, batch
+    # one problem per rank: problem g of the 8-problem diffusion sweep (kappa = 0.05 for the single-GPU headline)
+    kappa = 0.05 if world == 1 else batch.diffusion_sweep(batch.shard(world, rank, world)[0], max(world, 8))
     pde, solver = build_problem(kappa, args.steps + args.warmup)
     state = solver.initialize(pde)
     flt, dev = solver._device_filter, state.y.device_state
@@ -98,7 +111,7 @@ def main():
         ctx.synchronize()
         if dist is not None:
             import torch
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier()
             torch.cuda.synchronize()
 
     if args.warmup > 0:
@@ -114,17 +127,10 @@ def main():
     sig = np.array([o.diffusion_squared_local for o in infos])
     ok = bool(np.all(np.isfinite(means)) and np.all(np.isfinite(stds)) and all(o.info == -1 for o in infos))
     if dist is not None:
-        import torch
-        tmax = torch.tensor([wall], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        wall = float(tmax.item())
-        # the final gather of the per-problem read-outs (the only collective of the path)
-        payload = torch.from_numpy(np.concatenate([means.ravel(), stds.ravel(), sig])).cuda()
-        gathered = [torch.empty_like(payload) for _ in range(world)]
-        dist.all_gather(gathered, payload)
-        ok_t = torch.tensor([1.0 if ok else 0.0], device="cuda")
-        dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
-        ok = bool(ok_t.item() > 0.5)
+        wall = batch.max_over_ranks(wall, dist, device=coll_dev)
+        # the final gather of the per-problem read-outs -- the only collective of the path (RCCL over xGMI)
+        gathered = batch.gather_readouts(np.concatenate([means.ravel(), stds.ravel(), sig]), dist, device=coll_dev)
+        ok = bool(batch.max_over_ranks(0.0 if ok else 1.0, dist, device=coll_dev) == 0.0) and gathered.shape[0] == world
 
     if rank == 0:
         n, d = NU + 1, MESH_N
@@ -133,6 +139,11 @@ def main():
         flops = f_alg(D, m, n)
         step_ms_dev = dev_ms / args.steps
         achieved = flops / (step_ms_dev * 1e-3) / 1e12
+        traffic = None
+        try:   # HBM bytes per step from the committed PMC profile (rocprofv3 cannot run inside this process)
+            traffic = json.load(open(ROOT / "profiles" / "traffic.json"))["hbm_bytes_per_step"]
+        except Exception:
+            pass
         line = {
             "metric": "filter steps/sec, 1D heat N=512 nu=2 (white-noise EK1 predict+update)",
             "value": steps_per_s, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -143,9 +154,10 @@ def main():
                        "steps_in_one_call": args.steps, "valid": ok,
                        "device_ms_per_step": step_ms_dev},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
-                         "note": "whole step (all kernels of one predict+update), F_alg = %.4g flop/step, "
-                                 "duration = HIP events on the launch stream / steps" % flops},
+                         "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
+                         "note": "unit = one filter step (the 26-kernel graph of one predict+update): F_alg = %.4g "
+                                 "flop/step (SURVEY 8d), duration = HIP events on the launch stream / steps; "
+                                 "traffic = HBM bytes/step from profiles/ (PMC), B_alg = %.3g" % (flops, 3 * D * D * 8)},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

@@ -24,6 +24,7 @@ from .odetools import step as _step
 class _WhiteNoiseEK1Base(pdefilter.PDEFilter):
     _device_filter = None
     _device_pde = None
+    _error_models = None
     last_step_info = None
 
     # ------------------------------------------------------------------ cold path
@@ -112,7 +113,7 @@ class _WhiteNoiseEK1Base(pdefilter.PDEFilter):
     def _error_model(self, pde, dt):
         """Sq^-1 and diag(Sq) of `estimate_error` (white.py:153-162) in the Nordsieck frame of dt."""
         key = float(dt)
-        if key not in self._error_models:
+        if self._error_models is None or key not in self._error_models:
             d, nB = pde.L.shape[0], pde.B.shape[0]
             s, _ = self.iwp.nordsieck_preconditioner_1d_raw(dt)
             n = self.num_derivatives + 1
