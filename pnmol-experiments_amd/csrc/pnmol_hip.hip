@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "pnmol_hip.h"
@@ -187,12 +188,11 @@ __device__ __forceinline__ double bcast_lane(double x, int src) {
     return __hiloint2double(hi, lo);
 }
 
+// 1/sqrt(p): hardware seed + one cubically convergent step  y <- y + y e (1/2 + 3/8 e),  e = 1 - p y^2
 __device__ __forceinline__ double rsqrt_nr(double p) {
-    double y = __builtin_amdgcn_rsq(p);
-    double e = fma(-p * y, y, 1.0);
-    y = fma(0.5 * y, e, y);
-    e = fma(-p * y, y, 1.0);
-    return fma(0.5 * y, e, y);
+    const double y = __builtin_amdgcn_rsq(p);
+    const double e = fma(-(p * y), y, 1.0);
+    return fma(y * e, fma(0.375, e, 0.5), y);
 }
 
 //
@@ -201,37 +201,88 @@ __device__ __forceinline__ double rsqrt_nr(double p) {
 // measurement contributes nothing.  This is the noise-free Dirichlet row whose prior variance is already 0
 // (exact value 0, rounding noise of either sign in covariance form; the reference's square-root form gets
 // a tiny positive number and an equally negligible update).  Only a pivot that is negative at the 1e-3 level
-// of a significant row (or NaN) is reported through `info`.
-__device__ __forceinline__ void potrf32_inv_wave(double (&v)[NB], int lane, int* info, int base,
-                                                 double sdv /* lane q<32: |S_qq| of this block */, double smax) {
-    int bad = 0x7fffffff;
+// of a significant row (or NaN) is reported through `info` (checked for all 32 pivots at once after the loop).
+//
+// The stream is issue-bound (one wave, ~5 cycles per instruction), so it is kept lean: broadcasts are
+// software-pipelined in groups of four (no SGPR-hazard nops), the column step is branch-free (uniform
+// branches let LLVM sink earlier columns' updates to their first use, which serialises them and spills SGPRs)
+// and every column's updates are pinned by empty-asm register barriers.
+// Column step J.  The scaled column is written to LDS once; the first FAST updates (the ones the next pivot
+// depends on) use v_readlane broadcasts, the bulk reads its multipliers back from LDS two at a time
+// (same-address ds_read_b128 = broadcast), which halves the instruction count of the issue-bound stream.
+template <int J>
+__device__ __forceinline__ void potrf32_col(double (&v)[NB], int lane, double thr, double& pv, double* colbuf) {
+    constexpr int FAST = 3;
+    const double p = bcast_lane(v[J], J);
+    const bool ok = p > bcast_lane(thr, J);
+    pv = (lane == J) ? p : pv;
+#if defined(PNMOL_ABL) && PNMOL_ABL == 2
+    const double rsq = 0.5;
+#else
+    const double rsq = rsqrt_nr(ok ? p : 1.0);
+#endif
+    const double vj = ok ? v[J] * rsq : 0.0;
+    v[J] = vj;
+    const double nvj = -vj;
+    constexpr int KS = J + 1 + FAST;             // first column of the bulk
+    constexpr int KA = (KS + 1) & ~1;            // first even (16-byte aligned) bulk column
+    double* cb = colbuf + (J & 1) * 64;          // ping-pong: older reads of the other buffer may be in flight
+    if constexpr (KS < NB) cb[lane] = vj;        // lanes 32..63 land in the unused upper half
+    double2 bb[(NB - KA) / 2 > 0 ? (NB - KA) / 2 : 1];
+    double bodd = 0.0;
+    if constexpr (KS < NB) {
+        if constexpr (KS < KA) bodd = cb[KS];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        // branch-free column step (one basic block): uniform branches here let LLVM sink the updates of
-        // earlier columns down to their first use, which serialises them and spills SGPRs.
-        const double p = bcast_lane(v[j], j);
-        const double s0 = bcast_lane(sdv, j);
-        const bool ok = p > 1e-13 * s0;
-        const bool fatal = (!ok) & ((p != p) | ((p < -1e-3 * s0) & (s0 > 1e-12 * smax)));
-        bad = (fatal & (base + j < bad)) ? base + j : bad;
-        const double rs = rsqrt_nr(ok ? p : 1.0) * (ok ? 1.0 : 0.0);
-        const double vj = v[j] * rs;
-        v[j] = vj;
-        const double nvj = -vj;
-#pragma unroll
-        for (int k = j + 1; k < NB; ++k) v[k] = fma(nvj, bcast_lane(vj, k), v[k]);
-        // all updates of this column are complete here (register barrier, no instructions)
-#pragma unroll
-        for (int k = j + 1; k < NB; ++k) asm volatile("" : "+v"(v[k]));
+        for (int q = 0; q < (NB - KA) / 2; ++q) bb[q] = *reinterpret_cast<const double2*>(cb + KA + 2 * q);
     }
-    if (lane == 0 && bad != 0x7fffffff) atomicMin(info, bad);
+#pragma unroll
+    for (int k = J + 1; k < NB && k < KS; ++k) v[k] = fma(nvj, bcast_lane(vj, k), v[k]);
+#if defined(PNMOL_ABL) && PNMOL_ABL == 1
+    if constexpr (false) {
+#else
+    if constexpr (KS < NB) {
+#endif
+        if constexpr (KS < KA) v[KS] = fma(nvj, bodd, v[KS]);
+#pragma unroll
+        for (int q = 0; q < (NB - KA) / 2; ++q) {
+            v[KA + 2 * q] = fma(nvj, bb[q].x, v[KA + 2 * q]);
+            v[KA + 2 * q + 1] = fma(nvj, bb[q].y, v[KA + 2 * q + 1]);
+        }
+    }
+    // Register barriers (no instructions): the fast updates are complete here; the bulk may still be scheduled
+    // into the next column's pivot-chain latency, but no further (it is pinned at the end of the next column).
+#pragma unroll
+    for (int k = J + 1; k < NB && k < KS; ++k) asm volatile("" : "+v"(v[k]));
+    if constexpr (J > 0) {
+#pragma unroll
+        for (int k = J + FAST; k < NB; ++k) asm volatile("" : "+v"(v[k]));
+    }
+}
+
+template <int... Js>
+__device__ __forceinline__ void potrf32_cols(double (&v)[NB], int lane, double thr, double& pv, double* colbuf,
+                                             std::integer_sequence<int, Js...>) {
+    (potrf32_col<Js>(v, lane, thr, pv, colbuf), ...);
+}
+
+__device__ __forceinline__ void potrf32_inv_wave(double (&v)[NB], int lane, int* info, int base,
+                                                 double sdv /* lane q<32: |S_qq| of this block */, double smax,
+                                                 double* colbuf /* LDS, 128 doubles, 16-byte aligned */) {
+    const double thr = 1e-13 * sdv;
+    double pv = 1.0;  // lane j (< 32) records pivot j
+    potrf32_cols(v, lane, thr, pv, colbuf, std::make_integer_sequence<int, NB>{});
+    if (lane < NB) {
+        const bool fatal = !(pv > thr) && (!(pv == pv) || (pv < -1e-3 * sdv && sdv > 1e-12 * smax));
+        const unsigned long long m = __ballot(fatal);
+        if (m != 0 && lane == 0) atomicMin(info, base + __builtin_ctzll(m));
+    }
 }
 
 // wave 0 of a workgroup factorises the LDS tile T (row stride TLD) and writes L (upper zeroed) to
 // Fd (leading dim ld) and L^-1 to Li (32x32 row-major)
 __device__ __forceinline__ void diag_from_lds(const double* T, double* __restrict__ Fd, long ld,
                                               double* __restrict__ Li, int lane, int* info, int base,
-                                              const double* __restrict__ sdiag, double smax) {
+                                              const double* __restrict__ sdiag, double smax, double* colbuf) {
     double v[NB];
     const int q = lane & 31;
     const double sdv = fabs(sdiag[base + q]);
@@ -240,7 +291,7 @@ __device__ __forceinline__ void diag_from_lds(const double* T, double* __restric
         const double t = T[q * TLD + k];
         v[k] = (lane < 32) ? t : (k == q ? 1.0 : 0.0);
     }
-    potrf32_inv_wave(v, lane, info, base, sdv, smax);
+    potrf32_inv_wave(v, lane, info, base, sdv, smax, colbuf);
     if (lane < 32) {
 #pragma unroll
         for (int k = 0; k < NB; ++k) Fd[(long)q * ld + k] = (k <= q) ? v[k] : 0.0;
@@ -264,6 +315,7 @@ __global__ __launch_bounds__(64) void k_diag0(const double* __restrict__ G, doub
                                               double* __restrict__ sdiag /* [mp] diag S, then [mp] = max */,
                                               const int* __restrict__ ctr) {
     __shared__ double sT[NB * TLD];
+    __shared__ __attribute__((aligned(16))) double colbuf[128];
     const int lane = threadIdx.x;
     int* info = info_base + (*ctr - 1);
     double smax = 0.0;
@@ -277,7 +329,7 @@ __global__ __launch_bounds__(64) void k_diag0(const double* __restrict__ G, doub
     if (lane == 0) sdiag[ld] = smax;
     for (int e = lane; e < NB * NB; e += 64) sT[(e >> 5) * TLD + (e & 31)] = G[(long)(e >> 5) * ld + (e & 31)];
     __syncthreads();
-    diag_from_lds(sT, F, ld, Linv, lane, info, 0, sdiag, smax);
+    diag_from_lds(sT, F, ld, Linv, lane, info, 0, sdiag, smax, colbuf);
 }
 
 // panel j:  L_Ij = G_Ij Linv_j^T  for all row blocks I > j  (written to F by the c == 0 column),
@@ -287,7 +339,7 @@ __global__ __launch_bounds__(256) void k_panel(double* __restrict__ G, double* _
                                                double* __restrict__ Linv, int ld, int j, int CB, int RBS,
                                                int* info_base, const double* __restrict__ sdiag,
                                                const int* __restrict__ ctr) {
-    __shared__ double sA[NB * TLD], sB[NB * TLD], sI[NB * TLD];
+    __shared__ __attribute__((aligned(16))) double sA[NB * TLD], sB[NB * TLD], sI[NB * TLD];
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
     const int I = j + 1 + blockIdx.x;
     const int c = blockIdx.y;
@@ -295,13 +347,20 @@ __global__ __launch_bounds__(256) void k_panel(double* __restrict__ G, double* _
     const bool trailing = Kc < CB;
     if (trailing && I < RBS && I < Kc) return;  // strictly-upper tile of the symmetric part
 
+    const int wr = w >> 1, wc = w & 1;
+    const int fr = l & 15, fk = l >> 4;
+    // issue the loads of the tile to be updated first: their latency hides behind the panel product
+    double* gt = G + (long)I * NB * ld + (long)Kc * NB;
+    d4 acc = {0, 0, 0, 0};
+    if (trailing) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = gt[(long)(wr * 16 + fk + 4 * r) * ld + wc * 16 + fr];
+    }
     tile_g2s(Linv + (long)j * NB * NB, NB, sI, tid);
     tile_g2s(G + (long)I * NB * ld + (long)j * NB, ld, sA, tid);
     if (trailing) tile_g2s(G + (long)Kc * NB * ld + (long)j * NB, ld, sB, tid);
     __syncthreads();
 
-    const int wr = w >> 1, wc = w & 1;
-    const int fr = l & 15, fk = l >> 4;
     d4 li = {0, 0, 0, 0}, lk = {0, 0, 0, 0};
 #pragma unroll
     for (int s = 0; s < NB / 4; ++s) {
@@ -320,10 +379,6 @@ __global__ __launch_bounds__(256) void k_panel(double* __restrict__ G, double* _
     if (!trailing) return;
     __syncthreads();
 
-    double* gt = G + (long)I * NB * ld + (long)Kc * NB;
-    d4 acc;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = gt[(long)(wr * 16 + fk + 4 * r) * ld + wc * 16 + fr];
 #pragma unroll
     for (int s = 0; s < NB / 4; ++s)
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-sA[(wr * 16 + fr) * TLD + 4 * s + fk],
@@ -340,17 +395,36 @@ __global__ __launch_bounds__(256) void k_panel(double* __restrict__ G, double* _
     __syncthreads();
     if (w == 0)
         diag_from_lds(sA, F + ((long)(j + 1) * NB) * ld + (long)(j + 1) * NB, ld, Linv + (long)(j + 1) * NB * NB, l,
-                      info_base + (*ctr - 1), (j + 1) * NB, sdiag, sdiag[ld]);
+                      info_base + (*ctr - 1), (j + 1) * NB, sdiag, sdiag[ld], sI /* free by now */);
 }
+
+// ------------------------------------------------------------------------------------------
+// covariance down-date  P = P- - W W^T  on 16x16 point tiles x all n*n derivative blocks.
+// One workgroup (4 waves) per lower tile pair (J >= K).  The waves split the inner (measurement) dimension
+// in interleaved 8-column chunks; each wave streams its chunks global -> registers -> wave-private LDS ->
+// MFMA fragments with no workgroup barrier inside the loop; latency is hidden by occupancy (4 waves/SIMD).
+// Partial sums are combined through LDS in two rounds; waves 0/1 then write the tile and, transposed through
+// LDS so that it leaves as full 128-byte rows, its mirror image.  W = F + mp*ld (Dp x mp).
+// This launch subtracts the columns [8*c_begin, 8*c_end) of W; Ppred may alias Pout (a workgroup only reads
+// the tile it writes), which is how later column groups accumulate in place.
+// ------------------------------------------------------------------------------------------
+template <int N>
+struct DowndateCfg {
+    static constexpr int CW = 8;                    // chunk width (columns of W)
+    static constexpr int SLD = CW + 1;              // staging leading dim
+    static constexpr int STG = 2 * N * 16 * SLD;    // doubles of staging per wave
+    static constexpr int RED = N * N * 4 * 64;      // doubles of partial sums per wave
+    static constexpr int TLD16 = 17;                // transpose tile leading dim
+    static constexpr int LDS_D = (4 * STG > 2 * RED) ? 4 * STG : 2 * RED;
+};
 
 // second reduction round + epilogue of k_downdate for wave WV in {0,1}
 template <int N, int WV>
-__device__ __forceinline__ void downdate_finish(d4 (&acc)[N][N], double* smem, const double* __restrict__ Ppred,
-                                                double* __restrict__ Pout, double* __restrict__ var, int dp, long Dp,
-                                                int J, int K, int l) {
-    constexpr int RED = N * N * 4 * 64;
+__device__ __forceinline__ void downdate_finish(d4 (&acc)[N][N], double* smem, const double* Ppred, double* Pout,
+                                                double* __restrict__ var, int dp, long Dp, int J, int K, int l) {
+    using C = DowndateCfg<N>;
     const int fr = l & 15, fk = l >> 4;
-    double* wr = smem + (1 - WV) * RED;  // my contribution to the OTHER wave's registers
+    double* wr = smem + (1 - WV) * C::RED;  // my contribution to the OTHER wave's registers
 #pragma unroll
     for (int a = 0; a < N; ++a)
 #pragma unroll
@@ -358,50 +432,61 @@ __device__ __forceinline__ void downdate_finish(d4 (&acc)[N][N], double* smem, c
 #pragma unroll
             for (int q = 0; q < 2; ++q) wr[((a * N + b) * 2 + q) * 64 + l] = acc[a][b][(1 - WV) * 2 + q];
     __syncthreads();
-    const double* rdo = smem + WV * RED;
+    const double* rdo = smem + WV * C::RED;
+    double x[N][N][2];
 #pragma unroll
     for (int a = 0; a < N; ++a)
 #pragma unroll
         for (int b = 0; b < N; ++b)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                constexpr int dummy = 0;
-                (void)dummy;
-                const int r = WV * 2 + q;
-                const double sacc = acc[a][b][WV * 2 + q] + rdo[((a * N + b) * 2 + q) * 64 + l];
-                const int row = fk + 4 * r, col = fr;
-                const long gi = ((long)a * dp + J * 16 + row) * Dp + (long)b * dp + K * 16 + col;
-                const double x = Ppred[gi] - sacc;
-                Pout[gi] = x;
-                if (J != K) Pout[((long)b * dp + K * 16 + col) * Dp + (long)a * dp + J * 16 + row] = x;
-                if (J == K && a == b && row == col) var[a * dp + J * 16 + row] = x;
+                const int row = fk + 4 * (WV * 2 + q);
+                const long gi = ((long)a * dp + J * 16 + row) * Dp + (long)b * dp + K * 16 + fr;
+                x[a][b][q] = Ppred[gi] - (acc[a][b][WV * 2 + q] + rdo[((a * N + b) * 2 + q) * 64 + l]);
+                Pout[gi] = x[a][b][q];
+                if (J == K && a == b && row == fr) var[a * dp + J * 16 + row] = x[a][b][q];
             }
+    if (J == K) return;  // a diagonal tile pair is its own mirror image (workgroup-uniform)
+    // mirror image: block (b,a) of tile (K,J) = transpose.  This wave holds rows {fk + 4(2WV+q)} of each block;
+    // stage them in LDS as [col][row] and write rows of 8 consecutive doubles (the two waves fill the other half).
+    __syncthreads();  // both waves are done reading the reduction buffer
+    // one shared staging image [block][col][row]: wave WV contributes its rows 8WV..8WV+7 of every block
+    double* tp = smem;
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+#pragma unroll
+        for (int b = 0; b < N; ++b)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) tp[((a * N + b) * 16 + fr) * C::TLD16 + fk + 4 * (WV * 2 + q)] = x[a][b][q];
+    __syncthreads();
+    // wave WV writes the mirrored rows cc in [8 WV, 8 WV + 8): lane -> (cc, rr0 = 2 (l & 7)), one double2 per block:
+    // 8 full 128-byte rows per store instruction
+    const int cc = 8 * WV + (l >> 3), rr0 = (l & 7) * 2;
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+#pragma unroll
+        for (int b = 0; b < N; ++b) {
+            double2 v2;
+            v2.x = tp[((a * N + b) * 16 + cc) * C::TLD16 + rr0];
+            v2.y = tp[((a * N + b) * 16 + cc) * C::TLD16 + rr0 + 1];
+            *reinterpret_cast<double2*>(Pout + ((long)b * dp + K * 16 + cc) * Dp + (long)a * dp + J * 16 + rr0) = v2;
+        }
 }
 
-// ------------------------------------------------------------------------------------------
-// covariance down-date  P = P- - W W^T  on 16x16 point tiles x all n*n derivative blocks.
-// One workgroup (4 waves) per lower tile pair (J >= K).  The waves split the inner (measurement)
-// dimension in interleaved 16-column chunks; each wave streams its chunks global -> registers (prefetch of
-// the next chunk) -> wave-private LDS -> MFMA fragments, with no workgroup barrier inside the loop.
-// Partial sums are combined through LDS in two rounds; waves 0/1 write the tile and its mirror image.
-// W = F + mp*ld  (Dp x mp).
-// ------------------------------------------------------------------------------------------
 template <int N>
-__global__ __launch_bounds__(256) void k_downdate(const double* __restrict__ Ppred, const double* __restrict__ W,
-                                                  double* __restrict__ Pout, double* __restrict__ var,
-                                                  int dp, int mp) {
-    constexpr int SLD = 17;                      // staging leading dim (16 cols + pad)
-    constexpr int STG = 2 * N * 16 * SLD;        // doubles per wave staging
-    constexpr int RED = N * N * 4 * 64;          // doubles per wave of partial sums
-    constexpr int LDS_D = (4 * STG > 2 * RED) ? 4 * STG : 2 * RED;
-    __shared__ double smem[LDS_D];
+__global__ __launch_bounds__(256, 4) void k_downdate(const double* Ppred, const double* __restrict__ W, double* Pout,
+                                                     double* __restrict__ var, int dp, int mp, int c_begin,
+                                                     int c_end) {
+    using C = DowndateCfg<N>;
+    __shared__ __attribute__((aligned(16))) double smem[C::LDS_D];
+    static_assert(N * N * 16 * C::TLD16 <= C::LDS_D, "transpose staging must fit");
     const int J = blockIdx.y, K = blockIdx.x;
     if (K > J) return;
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
     const long Dp = (long)N * dp;
-    double* st = smem + w * STG;
+    double* st = smem + w * C::STG;
     const int fr = l & 15, fk = l >> 4;
-    const int lr = l >> 3, lc = (l & 7) * 2;  // staging load: 8 rows x 16 cols per instruction
+    const int lr = l >> 2, lc = (l & 3) * 2;  // staging load: 16 rows x 8 cols per instruction
 
     d4 acc[N][N];
 #pragma unroll
@@ -411,50 +496,31 @@ __global__ __launch_bounds__(256) void k_downdate(const double* __restrict__ Ppr
 
     const double* wa = W + ((long)J * 16 + lr) * mp + lc;
     const double* wb = W + ((long)K * 16 + lr) * mp + lc;
-    const long hstride = 8L * mp, astride = (long)dp * mp;
-    double2 pa[N][2], pb[N][2];
-    const int nchunks = mp / 16;
-    int chunk = w;
-    if (chunk < nchunks) {
+    const long astride = (long)dp * mp;
+    for (int chunk = c_begin + w; chunk < c_end; chunk += 4) {
+        double2 pa[N], pb[N];
 #pragma unroll
-        for (int a = 0; a < N; ++a)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                pa[a][h] = *reinterpret_cast<const double2*>(wa + a * astride + h * hstride + chunk * 16);
-                pb[a][h] = *reinterpret_cast<const double2*>(wb + a * astride + h * hstride + chunk * 16);
-            }
-    }
-    for (; chunk < nchunks; chunk += 4) {
+        for (int a = 0; a < N; ++a) {
+            pa[a] = *reinterpret_cast<const double2*>(wa + a * astride + chunk * C::CW);
+            pb[a] = *reinterpret_cast<const double2*>(wb + a * astride + chunk * C::CW);
+        }
         // registers -> wave-private LDS (the previous chunk's fragment reads are older in this wave's LDS queue)
 #pragma unroll
-        for (int a = 0; a < N; ++a)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int r = lr + 8 * h;
-                st[(a * 16 + r) * SLD + lc] = pa[a][h].x;
-                st[(a * 16 + r) * SLD + lc + 1] = pa[a][h].y;
-                st[((N + a) * 16 + r) * SLD + lc] = pb[a][h].x;
-                st[((N + a) * 16 + r) * SLD + lc + 1] = pb[a][h].y;
-            }
-        const int nxt = chunk + 4;
-        if (nxt < nchunks) {
-#pragma unroll
-            for (int a = 0; a < N; ++a)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    pa[a][h] = *reinterpret_cast<const double2*>(wa + a * astride + h * hstride + nxt * 16);
-                    pb[a][h] = *reinterpret_cast<const double2*>(wb + a * astride + h * hstride + nxt * 16);
-                }
+        for (int a = 0; a < N; ++a) {
+            st[(a * 16 + lr) * C::SLD + lc] = pa[a].x;
+            st[(a * 16 + lr) * C::SLD + lc + 1] = pa[a].y;
+            st[((N + a) * 16 + lr) * C::SLD + lc] = pb[a].x;
+            st[((N + a) * 16 + lr) * C::SLD + lc + 1] = pb[a].y;
         }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = 0; kk < C::CW / 4; ++kk) {
             double fa[N], fb[N];
 #pragma unroll
             for (int a = 0; a < N; ++a) {
-                fa[a] = st[(a * 16 + fr) * SLD + kk * 4 + fk];
-                fb[a] = st[((N + a) * 16 + fr) * SLD + kk * 4 + fk];
+                fa[a] = st[(a * 16 + fr) * C::SLD + kk * 4 + fk];
+                fb[a] = st[((N + a) * 16 + fr) * C::SLD + kk * 4 + fk];
             }
 #pragma unroll
             for (int a = 0; a < N; ++a)
@@ -468,7 +534,7 @@ __global__ __launch_bounds__(256) void k_downdate(const double* __restrict__ Ppr
     // round 1: waves 2,3 -> LDS, waves 0,1 accumulate
     __syncthreads();
     if (w >= 2) {
-        double* rd = smem + (w - 2) * RED;
+        double* rd = smem + (w - 2) * C::RED;
 #pragma unroll
         for (int a = 0; a < N; ++a)
 #pragma unroll
@@ -479,7 +545,7 @@ __global__ __launch_bounds__(256) void k_downdate(const double* __restrict__ Ppr
     __syncthreads();
     if (w >= 2) return;
     {
-        const double* rd = smem + w * RED;
+        const double* rd = smem + w * C::RED;
 #pragma unroll
         for (int a = 0; a < N; ++a)
 #pragma unroll
@@ -592,6 +658,9 @@ static double nordsieck_scale(int nu, int a, double dt) {  // base/iwp.py:55-62
 struct pnmol_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;   // runs the down-date column groups beside the factorisation chain
+    hipEvent_t ev[8] = {};
+    int ev_next = 0;
     std::string err;
 };
 
@@ -626,6 +695,10 @@ struct pnmol_filter {
     };
     std::vector<GraphEntry> graphs;
     int graph_chunk = 10;  // steps per captured graph (even); 0 disables graphs
+    // Run down-date column groups on a side stream beside the factorisation chain.  Measured on MI355X / ROCm 7.2
+    // (N=512): 390 us/step with, 328 us/step without -- the concurrent groups slow the latency-critical panel
+    // kernels by more than they hide (1059 us with stream priorities inside a graph) -> off by default.
+    bool overlap = false;
 };
 
 struct pnmol_state {
@@ -663,18 +736,51 @@ int launch_step(pnmol_filter* f, const double* Pin, const double* min, double fr
     const long rowI0 = (long)mp + Dp + NB;
     k_sbuild<<<dim3((mp + 255) / 256, 2 * mp), 256, 0, st>>>(f->G, f->rdiag, f->Rdense, mm, rowI0);
     k_diag0<<<1, 64, 0, st>>>(f->G, f->F, f->Linv, mp, f->info, f->sdiag, f->ctr);
+    // The columns of W belonging to finished panels are final, so the down-date P -= W W^T is cut into column
+    // groups that run on the side stream while the (latency-bound) chain continues; only the last, small group
+    // is left after the chain.  Group g covers panels [gb[g], gb[g+1]).
+    const double* W = f->F + (long)mp * mp;
+    hipStream_t sd = ctx->side;
+    int gb[8], ng = 0;
+    {
+        const int CB = f->CB;
+        if (f->overlap && CB >= 8) {
+            const int cuts[] = {0, (CB * 6 + 8) / 17, (CB * 11 + 8) / 17, (CB * 15 + 8) / 17, CB};
+            for (int q = 0; q < 5; ++q)
+                if (ng == 0 || cuts[q] > gb[ng - 1]) gb[ng++] = cuts[q];
+        } else {
+            gb[ng++] = 0, gb[ng++] = CB;
+        }
+    }
+    int g = 0;  // next group to launch
+    bool forked = false;
+    auto launch_group = [&](hipStream_t s_, int gi) {
+        k_downdate<N><<<dim3(dp / 16, dp / 16), 256, 0, s_>>>(gi == 0 ? f->Ppred : Pout, W, Pout, varout, dp, mp,
+                                                              (NB / 8) * gb[gi], (NB / 8) * gb[gi + 1]);
+    };
     for (int j = 0; j < f->CB; ++j) {
         const int nrb = f->RT - (j + 1);
         const int ncb = f->CB - 1 - j > 0 ? f->CB - 1 - j : 1;
         k_panel<<<dim3(nrb, ncb), 256, 0, st>>>(f->G, f->F, f->Linv, mp, j, f->CB, f->RBS, f->info, f->sdiag, f->ctr);
+        if (ng > 2 && g < ng - 2 && j + 1 == gb[g + 1]) {  // panels of group g are final: fork
+            hipEvent_t ev = ctx->ev[ctx->ev_next++ & 7];
+            (void)hipEventRecord(ev, st);
+            (void)hipStreamWaitEvent(sd, ev, 0);
+            launch_group(sd, g++);
+            forked = true;
+        }
     }
-    const double* W = f->F + (long)mp * mp;
     const double* r = f->F + ((long)mp + Dp) * mp;
     const double* LinvT = f->F + rowI0 * mp;
     const bool have_sq = (f->Sqinv != nullptr && f->sq_dt == dt);
     k_vecops<<<(unsigned)((Dp + mp + 3) / 4), 256, 0, st>>>(f->mpred, W, r, LinvT, f->zbuf, have_sq ? f->Sqinv : nullptr,
                                                             mout, f->part, mp, Dp);
-    k_downdate<N><<<dim3(dp / 16, dp / 16), 256, 0, st>>>(f->Ppred, W, Pout, varout, dp, mp);
+    if (forked) {  // join: the remaining group(s) read what the side stream accumulated
+        hipEvent_t ev = ctx->ev[ctx->ev_next++ & 7];
+        (void)hipEventRecord(ev, sd);
+        (void)hipStreamWaitEvent(st, ev, 0);
+    }
+    for (; g < ng - 1; ++g) launch_group(st, g);
     k_readout<<<(f->d + 255) / 256, 256, 0, st>>>(mout, varout, record ? f->rec_means : nullptr,
                                                   record ? f->rec_stds : nullptr, nordsieck_scale(f->nu, 0, dt), f->d,
                                                   f->part, f->rec, mp, f->ctr);
@@ -807,8 +913,11 @@ int pnmol_ctx_create(int device, pnmol_ctx** out) {
     if (hipSetDevice(device) != hipSuccess) return -2;
     pnmol_ctx* ctx = new pnmol_ctx();
     ctx->device = device;
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
-        delete ctx;
+    bool okc = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
+               hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) == hipSuccess;
+    for (auto& e : ctx->ev) okc = okc && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    if (!okc) {
+        pnmol_ctx_destroy(ctx);
         return -2;
     }
     *out = ctx;
@@ -819,6 +928,9 @@ int pnmol_ctx_destroy(pnmol_ctx* ctx) {
     if (!ctx) return -1;
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
+    if (ctx->side) hipStreamDestroy(ctx->side);
+    for (auto& e : ctx->ev)
+        if (e) hipEventDestroy(e);
     delete ctx;
     return 0;
 }
@@ -957,6 +1069,7 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
     FCHK(hipMalloc(&f->part, sizeof(double) * 3 * mp));
     FCHK(hipMalloc(&f->ctr, sizeof(int)));
     if (const char* gc = std::getenv("PNMOL_HIP_GRAPH_CHUNK")) f->graph_chunk = std::atoi(gc) / 2 * 2;
+    if (const char* ov = std::getenv("PNMOL_HIP_OVERLAP")) f->overlap = std::atoi(ov) != 0;
     FCHK(hipMalloc(&f->sdiag, sizeof(double) * (mp + 1)));
     FCHK(hipMemcpy(f->ell_col, ecol.data(), sizeof(int) * ecol.size(), hipMemcpyHostToDevice));
     FCHK(hipMemcpy(f->ell_val, eval.data(), sizeof(double) * eval.size(), hipMemcpyHostToDevice));
