@@ -46,14 +46,67 @@ struct IwpConsts {
 };
 
 // ------------------------------------------------------------------------------------------
-// predict:  P-_ab = sum_ce A1[a,c] A1[b,e] ts_c ts_e P_ce + Q1[a,b] K      (HBM-bound pass)
+// H apply (stencil gather).  ELL arrays are [e*mp + i].
+// ------------------------------------------------------------------------------------------
+struct MeasModel {
+    const int* ell_col;
+    const double* ell_val;
+    int w, d, m, dp, mp;
+    double c0, c1;
+};
+
+// (H x)[i] for a state-indexed vector x (global or LDS)
+__device__ __forceinline__ double h_row_dot(const MeasModel& mm, int i, const double* x) {
+    double v = 0.0;
+    if (i < mm.d) v = mm.c1 * x[mm.dp + i];
+    for (int e = 0; e < mm.w; ++e) {
+        const int cidx = mm.ell_col[e * mm.mp + i];
+        if (cidx >= 0) v += mm.c0 * mm.ell_val[e * mm.mp + i] * x[cidx];
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// K1  predict:  P-_ab = sum_ce A1[a,c] A1[b,e] ts_c ts_e P_ce + Q1[a,b] K      (HBM-bound pass)
+// One extra workgroup (blockIdx.y == 0) does the vector work of the step start: m- = A m, z = H m- + shift
+// (into the z row of G and zbuf) and advances the step counter: every later kernel of this step writes its
+// per-step outputs to slot *ctr - 1, so all steps launch with identical arguments (hipGraph replay).
 // ------------------------------------------------------------------------------------------
 template <int N>
 __global__ __launch_bounds__(256) void k_predict(const double* __restrict__ Pin, double* __restrict__ Pout,
-                                                 const double* __restrict__ Kg, IwpConsts c, int dp) {
-    const int k = blockIdx.x * 32 + threadIdx.x;
-    const int j = blockIdx.y * 8 + threadIdx.y;
+                                                 const double* __restrict__ Kg, IwpConsts c, int dp,
+                                                 const double* __restrict__ min, double* __restrict__ mpred,
+                                                 const double* __restrict__ shift, double* __restrict__ G,
+                                                 double* __restrict__ zbuf, MeasModel mm, int* __restrict__ ctr) {
     const long Dp = (long)N * dp;
+    if (blockIdx.y == 0) {  // dispatched first, so its short dependent-load chain hides behind the tile blocks
+        if (blockIdx.x != 0) return;
+        extern __shared__ double mpl[];  // predicted mean, Dp doubles
+        const int tid = threadIdx.y * 32 + threadIdx.x;
+        for (int j = tid; j < dp; j += 256) {
+            double x[N];
+#pragma unroll
+            for (int a = 0; a < N; ++a) x[a] = c.ts[a] * min[a * dp + j];
+#pragma unroll
+            for (int a = 0; a < N; ++a) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int q = 0; q < N; ++q) sacc += c.A1[a * MAXN + q] * x[q];
+                mpl[a * dp + j] = sacc;
+                mpred[a * dp + j] = sacc;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < mm.mp; i += 256) {
+            const double v = (i < mm.m) ? h_row_dot(mm, i, mpl) + shift[i] : 0.0;
+            G[((long)mm.mp + Dp) * mm.mp + i] = v;
+            zbuf[i] = v;
+        }
+        if (tid == 0) *ctr += 1;
+        return;
+    }
+    const int k = blockIdx.x * 32 + threadIdx.x;
+    const int j = (blockIdx.y - 1) * 8 + threadIdx.y;
     double X[N][N];
 #pragma unroll
     for (int a = 0; a < N; ++a)
@@ -65,113 +118,36 @@ __global__ __launch_bounds__(256) void k_predict(const double* __restrict__ Pin,
     for (int a = 0; a < N; ++a)
 #pragma unroll
         for (int e = 0; e < N; ++e) {
-            double s = 0.0;
+            double sacc = 0.0;
 #pragma unroll
-            for (int q = 0; q < N; ++q) s += c.A1[a * MAXN + q] * X[q][e];
-            T[a][e] = s;
+            for (int q = 0; q < N; ++q) sacc += c.A1[a * MAXN + q] * X[q][e];
+            T[a][e] = sacc;
         }
 #pragma unroll
     for (int a = 0; a < N; ++a)
 #pragma unroll
         for (int b = 0; b < N; ++b) {
-            double s = c.Q1[a * MAXN + b] * kjk;
+            double sacc = c.Q1[a * MAXN + b] * kjk;
 #pragma unroll
-            for (int e = 0; e < N; ++e) s += T[a][e] * c.A1[b * MAXN + e];
-            Pout[((long)a * dp + j) * Dp + (long)b * dp + k] = s;
+            for (int e = 0; e < N; ++e) sacc += T[a][e] * c.A1[b * MAXN + e];
+            Pout[((long)a * dp + j) * Dp + (long)b * dp + k] = sacc;
         }
 }
 
-template <int N>
-__global__ void k_predict_mean(const double* __restrict__ min, double* __restrict__ mout, IwpConsts c, int dp) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= dp) return;
-    double x[N];
-#pragma unroll
-    for (int a = 0; a < N; ++a) x[a] = c.ts[a] * min[a * dp + j];
-#pragma unroll
-    for (int a = 0; a < N; ++a) {
-        double s = 0.0;
-#pragma unroll
-        for (int q = 0; q < N; ++q) s += c.A1[a * MAXN + q] * x[q];
-        mout[a * dp + j] = s;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// H apply (stencil gather).  ELL arrays are [e*mp + i].
-// ------------------------------------------------------------------------------------------
-struct MeasModel {
-    const int* ell_col;
-    const double* ell_val;
-    int w, d, m, dp, mp;
-    double c0, c1;
-};
-
-// G[mp + row, i] = (P- H^T)[row, i]
-__global__ __launch_bounds__(256) void k_pht(const double* __restrict__ Ppred, double* __restrict__ G, MeasModel mm,
-                                             long Dp) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const long row = blockIdx.y;
-    if (i >= mm.mp) return;
-    const double* prow = Ppred + row * Dp;
+// S[ip, i] = (H P- H^T)[ip, i] + R[ip, i] straight from P- (identity on the padding).  Same association order as
+// H (P- H^T): inner sum over the stencil of column i, outer sum over the stencil of row ip.
+__device__ __forceinline__ double s_entry(const double* __restrict__ Ppred, long Dp, const MeasModel& mm, int ip, int i,
+                                          const double* __restrict__ rdiag, const double* __restrict__ Rdense) {
+    if (ip >= mm.m || i >= mm.m) return (ip == i) ? 1.0 : 0.0;
     double v = 0.0;
-    if (i < mm.m) {
-        if (i < mm.d) v = mm.c1 * prow[mm.dp + i];
-        for (int e = 0; e < mm.w; ++e) {
-            const int cidx = mm.ell_col[e * mm.mp + i];
-            if (cidx >= 0) v += mm.c0 * mm.ell_val[e * mm.mp + i] * prow[cidx];
-        }
+    if (ip < mm.d) v = mm.c1 * h_row_dot(mm, i, Ppred + (long)(mm.dp + ip) * Dp);
+    for (int e = 0; e < mm.w; ++e) {
+        const int cidx = mm.ell_col[e * mm.mp + ip];
+        if (cidx >= 0) v += mm.c0 * mm.ell_val[e * mm.mp + ip] * h_row_dot(mm, i, Ppred + (long)cidx * Dp);
     }
-    G[((long)mm.mp + row) * mm.mp + i] = v;
-}
-
-// z = H m- + shift, into the extra row block of G and into zbuf
-// Also advances the step counter: every later kernel of this step writes its per-step outputs to slot
-// *ctr - 1, so all steps launch with identical arguments and a captured hipGraph can be replayed.
-__global__ void k_zrow(const double* __restrict__ mpred, const double* __restrict__ shift, double* __restrict__ G,
-                       double* __restrict__ zbuf, MeasModel mm, long Dp, int* __restrict__ ctr) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) *ctr += 1;
-    if (i >= mm.mp) return;
-    double v = 0.0;
-    if (i < mm.m) {
-        if (i < mm.d) v = mm.c1 * mpred[mm.dp + i];
-        for (int e = 0; e < mm.w; ++e) {
-            const int cidx = mm.ell_col[e * mm.mp + i];
-            if (cidx >= 0) v += mm.c0 * mm.ell_val[e * mm.mp + i] * mpred[cidx];
-        }
-        v += shift[i];
-    }
-    G[((long)mm.mp + Dp) * mm.mp + i] = v;
-    zbuf[i] = v;
-}
-
-// G[ip, i] = S[ip, i] = (H (P- H^T))[ip, i] + R[ip, i];  identity on the padding.
-// Rows ip >= mp (grid y = 2*mp) re-initialise the trailing identity block of G, which the sweep
-// turns into Ls^-T (rows of the tall matrix transform as row * Ls^-T).
-__global__ __launch_bounds__(256) void k_sbuild(double* __restrict__ G, const double* __restrict__ rdiag,
-                                                const double* __restrict__ Rdense, MeasModel mm, long rowI0) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int ip = blockIdx.y;
-    if (i >= mm.mp) return;
-    if (ip >= mm.mp) {
-        G[(rowI0 + ip - mm.mp) * mm.mp + i] = (ip - mm.mp == i) ? 1.0 : 0.0;
-        return;
-    }
-    double v;
-    if (ip < mm.m && i < mm.m) {
-        v = 0.0;
-        if (ip < mm.d) v = mm.c1 * G[((long)mm.mp + mm.dp + ip) * mm.mp + i];
-        for (int e = 0; e < mm.w; ++e) {
-            const int cidx = mm.ell_col[e * mm.mp + ip];
-            if (cidx >= 0) v += mm.c0 * mm.ell_val[e * mm.mp + ip] * G[((long)mm.mp + cidx) * mm.mp + i];
-        }
-        if (ip == i) v += rdiag[i];
-        if (Rdense) v += Rdense[(long)ip * mm.mp + i];
-    } else {
-        v = (ip == i) ? 1.0 : 0.0;
-    }
-    G[(long)ip * mm.mp + i] = v;
+    if (ip == i) v += rdiag[i];
+    if (Rdense) v += Rdense[(long)ip * mm.mp + i];
+    return v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -309,15 +285,38 @@ __device__ __forceinline__ void tile_g2s(const double* __restrict__ g, long ld, 
     }
 }
 
-// first diagonal block: F[0,0] = chol(G[0,0]), Linv[0] = its inverse   (one wave)
+// ------------------------------------------------------------------------------------------
+// K2  build the tall matrix G = [S; P- H^T; z^T; I].  Roles by blockIdx.y:
+//   [0, Dp)             row of P- H^T                       (stencil gather along the row of P-)
+//   [Dp, Dp+mp)         row of S = H P- H^T + R             (straight from P-, see s_entry)
+//   [Dp+mp, Dp+2mp)     row of the trailing identity block  (the sweep turns it into Ls^-T)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_front(const double* __restrict__ Ppred, double* __restrict__ G,
+                                               const double* __restrict__ rdiag, const double* __restrict__ Rdense,
+                                               MeasModel mm, long Dp) {
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * 256 + tid;
+    const long y = blockIdx.y;
+    const int mp = mm.mp;
+    if (y < Dp) {
+        if (i < mp) G[((long)mp + y) * mp + i] = (i < mm.m) ? h_row_dot(mm, i, Ppred + y * Dp) : 0.0;
+        return;
+    }
+    if (y < Dp + mp) {
+        if (i < mp) G[(y - Dp) * mp + i] = s_entry(Ppred, Dp, mm, (int)(y - Dp), i, rdiag, Rdense);
+        return;
+    }
+    const long q = y - Dp - mp;
+    if (i < mp) G[((long)mp + Dp + NB + q) * mp + i] = (q == i) ? 1.0 : 0.0;
+}
+
+// first diagonal block: diag(S) -> sdiag, its max -> sdiag[mp]; F[0,0] = chol(G[0,0]), Linv[0] = its inverse
 __global__ __launch_bounds__(64) void k_diag0(const double* __restrict__ G, double* __restrict__ F,
                                               double* __restrict__ Linv, int ld, int* info_base,
-                                              double* __restrict__ sdiag /* [mp] diag S, then [mp] = max */,
-                                              const int* __restrict__ ctr) {
+                                              double* __restrict__ sdiag, const int* __restrict__ ctr) {
     __shared__ double sT[NB * TLD];
     __shared__ __attribute__((aligned(16))) double colbuf[128];
     const int lane = threadIdx.x;
-    int* info = info_base + (*ctr - 1);
     double smax = 0.0;
     for (int e = lane; e < ld; e += 64) {
         const double x = G[(long)e * ld + e];
@@ -329,7 +328,7 @@ __global__ __launch_bounds__(64) void k_diag0(const double* __restrict__ G, doub
     if (lane == 0) sdiag[ld] = smax;
     for (int e = lane; e < NB * NB; e += 64) sT[(e >> 5) * TLD + (e & 31)] = G[(long)(e >> 5) * ld + (e & 31)];
     __syncthreads();
-    diag_from_lds(sT, F, ld, Linv, lane, info, 0, sdiag, smax, colbuf);
+    diag_from_lds(sT, F, ld, Linv, lane, info_base + (*ctr - 1), 0, sdiag, smax, colbuf);
 }
 
 // panel j:  L_Ij = G_Ij Linv_j^T  for all row blocks I > j  (written to F by the c == 0 column),
@@ -396,6 +395,52 @@ __global__ __launch_bounds__(256) void k_panel(double* __restrict__ G, double* _
     if (w == 0)
         diag_from_lds(sA, F + ((long)(j + 1) * NB) * ld + (long)(j + 1) * NB, ld, Linv + (long)(j + 1) * NB * NB, l,
                       info_base + (*ctr - 1), (j + 1) * NB, sdiag, sdiag[ld], sI /* free by now */);
+}
+
+// One wave per row of four matrix-vector products that all need the finished sweep (role of the extra
+// blockIdx.y rows of k_downdate):
+//   rows [0, Dp)          m = m- - W r                               (mean update, white.py:123)
+//   rows [Dp, Dp+mp)      part[0][i] = r_i^2                         (whitened residual)
+//                         part[1][i] = (Ls^-T z)_i^2                 (white.py:125 with the Cholesky factor)
+//                         part[2][i] = z_i (Sq^-1 z)_i               (estimate_error, white.py:153-162)
+struct VecArgs {
+    const double* mpred;
+    const double* r;
+    const double* LinvT;
+    const double* z;
+    const double* Sqinv;
+    double* mout;
+    double* part;
+};
+
+__device__ __forceinline__ void vecops_rows(const VecArgs& va, const double* __restrict__ W, int mp, long Dp,
+                                            long wave_row, int l) {
+    const long row = wave_row;
+    if (row < Dp) {
+        double sacc = 0.0;
+        for (int i = l; i < mp; i += 64) sacc += W[row * mp + i] * va.r[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
+        if (l == 0) va.mout[row] = va.mpred[row] - sacc;
+    } else if (row < Dp + mp) {
+        const long q = row - Dp;
+        double x = 0.0, y = 0.0;
+        for (int i = l; i < mp; i += 64) {
+            const double zi = va.z[i];
+            x += va.LinvT[q * mp + i] * zi;
+            if (va.Sqinv) y += va.Sqinv[q * mp + i] * zi;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            x += __shfl_xor(x, o);
+            y += __shfl_xor(y, o);
+        }
+        if (l == 0) {
+            va.part[q] = va.r[q] * va.r[q];
+            va.part[mp + q] = x * x;
+            va.part[2 * mp + q] = va.z[q] * y;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -474,16 +519,20 @@ __device__ __forceinline__ void downdate_finish(d4 (&acc)[N][N], double* smem, c
 }
 
 template <int N>
-__global__ __launch_bounds__(256, 4) void k_downdate(const double* Ppred, const double* __restrict__ W, double* Pout,
+__global__ __launch_bounds__(256, (N <= 3 ? 4 : 1)) void k_downdate(const double* Ppred, const double* __restrict__ W, double* Pout,
                                                      double* __restrict__ var, int dp, int mp, int c_begin,
-                                                     int c_end) {
+                                                     int c_end, VecArgs va) {
     using C = DowndateCfg<N>;
     __shared__ __attribute__((aligned(16))) double smem[C::LDS_D];
     static_assert(N * N * 16 * C::TLD16 <= C::LDS_D, "transpose staging must fit");
-    const int J = blockIdx.y, K = blockIdx.x;
-    if (K > J) return;
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
     const long Dp = (long)N * dp;
+    if ((int)blockIdx.y >= dp / 16) {  // vector-op rows ride in the same launch (4 rows per workgroup)
+        vecops_rows(va, W, mp, Dp, ((long)(blockIdx.y - dp / 16) * (dp / 16) + blockIdx.x) * 4 + w, l);
+        return;
+    }
+    const int J = blockIdx.y, K = blockIdx.x;
+    if (K > J) return;
     double* st = smem + w * C::STG;
     const int fr = l & 15, fk = l >> 4;
     const int lr = l >> 2, lc = (l & 3) * 2;  // staging load: 16 rows x 8 cols per instruction
@@ -562,47 +611,8 @@ __global__ __launch_bounds__(256, 4) void k_downdate(const double* Ppred, const 
         downdate_finish<N, 1>(acc, smem, Ppred, Pout, var, dp, Dp, J, K, l);
 }
 
-// One wave per row of four matrix-vector products that all need the finished sweep:
-//   rows [0, Dp)          m = m- - W r                               (mean update, white.py:123)
-//   rows [Dp, Dp+mp)      part[0][i] = r_i^2                         (whitened residual)
-//                         part[1][i] = (Ls^-T z)_i^2                 (white.py:125 with the Cholesky factor)
-//                         part[2][i] = z_i (Sq^-1 z)_i               (estimate_error, white.py:153-162)
-__global__ __launch_bounds__(256) void k_vecops(const double* __restrict__ mpred, const double* __restrict__ W,
-                                                const double* __restrict__ r, const double* __restrict__ LinvT,
-                                                const double* __restrict__ z, const double* __restrict__ Sqinv,
-                                                double* __restrict__ mout, double* __restrict__ part, int mp,
-                                                long Dp) {
-    const int l = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row < Dp) {
-        double s = 0.0;
-        for (int i = l; i < mp; i += 64) s += W[row * mp + i] * r[i];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (l == 0) mout[row] = mpred[row] - s;
-    } else if (row < Dp + mp) {
-        const long q = row - Dp;
-        double x = 0.0, y = 0.0;
-        for (int i = l; i < mp; i += 64) {
-            const double zi = z[i];
-            x += LinvT[q * mp + i] * zi;
-            if (Sqinv) y += Sqinv[q * mp + i] * zi;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            x += __shfl_xor(x, o);
-            y += __shfl_xor(y, o);
-        }
-        if (l == 0) {
-            part[q] = r[q] * r[q];
-            part[mp + q] = x * x;
-            part[2 * mp + q] = z[q] * y;
-        }
-    }
-}
-
 // per-step read-out of the parity quantities (experiments/figure1.py:76-80), raw coordinates;
-// block 0 also reduces the partial sums of k_vecops into rec[0..2] (fixed order: deterministic)
+// block 0 also reduces the partial sums of the vector-op rows into rec[0..2] (fixed order: deterministic)
 __global__ __launch_bounds__(256) void k_readout(const double* __restrict__ mean, const double* __restrict__ var,
                                                  double* __restrict__ means_base, double* __restrict__ stds_base,
                                                  double s0, int d, const double* __restrict__ part,
@@ -658,9 +668,6 @@ static double nordsieck_scale(int nu, int a, double dt) {  // base/iwp.py:55-62
 struct pnmol_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t side = nullptr;   // runs the down-date column groups beside the factorisation chain
-    hipEvent_t ev[8] = {};
-    int ev_next = 0;
     std::string err;
 };
 
@@ -695,10 +702,7 @@ struct pnmol_filter {
     };
     std::vector<GraphEntry> graphs;
     int graph_chunk = 10;  // steps per captured graph (even); 0 disables graphs
-    // Run down-date column groups on a side stream beside the factorisation chain.  Measured on MI355X / ROCm 7.2
-    // (N=512): 390 us/step with, 328 us/step without -- the concurrent groups slow the latency-critical panel
-    // kernels by more than they hide (1059 us with stream priorities inside a graph) -> off by default.
-    bool overlap = false;
+
 };
 
 struct pnmol_state {
@@ -729,58 +733,28 @@ int launch_step(pnmol_filter* f, const double* Pin, const double* min, double fr
     const int dp = f->dp, mp = f->mp;
     const long Dp = f->Dp;
 
-    k_predict<N><<<dim3(dp / 32, dp / 8), dim3(32, 8), 0, st>>>(Pin, f->Ppred, f->Kg, c, dp);
-    k_predict_mean<N><<<(dp + 255) / 256, 256, 0, st>>>(min, f->mpred, c, dp);
-    k_pht<<<dim3((mp + 255) / 256, (unsigned)Dp), 256, 0, st>>>(f->Ppred, f->G, mm, Dp);
-    k_zrow<<<(mp + 255) / 256, 256, 0, st>>>(f->mpred, f->shift, f->G, f->zbuf, mm, Dp, f->ctr);
-    const long rowI0 = (long)mp + Dp + NB;
-    k_sbuild<<<dim3((mp + 255) / 256, 2 * mp), 256, 0, st>>>(f->G, f->rdiag, f->Rdense, mm, rowI0);
+    // K1: P- = A P A^T + Q  (+ one workgroup: m-, z, step counter)
+    k_predict<N><<<dim3(dp / 32, dp / 8 + 1), dim3(32, 8), sizeof(double) * Dp, st>>>(
+        Pin, f->Ppred, f->Kg, c, dp, min, f->mpred, f->shift, f->G, f->zbuf, mm, f->ctr);
+    // K2: G = [S; P-H^T; z; I] and the first diagonal block
+    k_front<<<dim3((mp + 255) / 256, (unsigned)(Dp + 2 * mp)), 256, 0, st>>>(f->Ppred, f->G, f->rdiag, f->Rdense, mm, Dp);
     k_diag0<<<1, 64, 0, st>>>(f->G, f->F, f->Linv, mp, f->info, f->sdiag, f->ctr);
-    // The columns of W belonging to finished panels are final, so the down-date P -= W W^T is cut into column
-    // groups that run on the side stream while the (latency-bound) chain continues; only the last, small group
-    // is left after the chain.  Group g covers panels [gb[g], gb[g+1]).
-    const double* W = f->F + (long)mp * mp;
-    hipStream_t sd = ctx->side;
-    int gb[8], ng = 0;
-    {
-        const int CB = f->CB;
-        if (f->overlap && CB >= 8) {
-            const int cuts[] = {0, (CB * 6 + 8) / 17, (CB * 11 + 8) / 17, (CB * 15 + 8) / 17, CB};
-            for (int q = 0; q < 5; ++q)
-                if (ng == 0 || cuts[q] > gb[ng - 1]) gb[ng++] = cuts[q];
-        } else {
-            gb[ng++] = 0, gb[ng++] = CB;
-        }
-    }
-    int g = 0;  // next group to launch
-    bool forked = false;
-    auto launch_group = [&](hipStream_t s_, int gi) {
-        k_downdate<N><<<dim3(dp / 16, dp / 16), 256, 0, s_>>>(gi == 0 ? f->Ppred : Pout, W, Pout, varout, dp, mp,
-                                                              (NB / 8) * gb[gi], (NB / 8) * gb[gi + 1]);
-    };
+    // K3: right-looking sweep, one launch per 32-column panel
     for (int j = 0; j < f->CB; ++j) {
         const int nrb = f->RT - (j + 1);
         const int ncb = f->CB - 1 - j > 0 ? f->CB - 1 - j : 1;
         k_panel<<<dim3(nrb, ncb), 256, 0, st>>>(f->G, f->F, f->Linv, mp, j, f->CB, f->RBS, f->info, f->sdiag, f->ctr);
-        if (ng > 2 && g < ng - 2 && j + 1 == gb[g + 1]) {  // panels of group g are final: fork
-            hipEvent_t ev = ctx->ev[ctx->ev_next++ & 7];
-            (void)hipEventRecord(ev, st);
-            (void)hipStreamWaitEvent(sd, ev, 0);
-            launch_group(sd, g++);
-            forked = true;
-        }
     }
-    const double* r = f->F + ((long)mp + Dp) * mp;
-    const double* LinvT = f->F + rowI0 * mp;
+    // K4: P = P- - W W^T (tiles) and, in extra blockIdx.y rows of the same launch, the vector ops
+    const long rowI0 = (long)mp + Dp + NB;
+    const double* W = f->F + (long)mp * mp;
     const bool have_sq = (f->Sqinv != nullptr && f->sq_dt == dt);
-    k_vecops<<<(unsigned)((Dp + mp + 3) / 4), 256, 0, st>>>(f->mpred, W, r, LinvT, f->zbuf, have_sq ? f->Sqinv : nullptr,
-                                                            mout, f->part, mp, Dp);
-    if (forked) {  // join: the remaining group(s) read what the side stream accumulated
-        hipEvent_t ev = ctx->ev[ctx->ev_next++ & 7];
-        (void)hipEventRecord(ev, sd);
-        (void)hipStreamWaitEvent(st, ev, 0);
-    }
-    for (; g < ng - 1; ++g) launch_group(st, g);
+    VecArgs va{f->mpred, f->F + ((long)mp + Dp) * mp, f->F + rowI0 * mp, f->zbuf, have_sq ? f->Sqinv : nullptr,
+               mout, f->part};
+    const int tiles = dp / 16;
+    const int vrows = (int)(((Dp + mp + 3) / 4 + tiles - 1) / tiles);
+    k_downdate<N><<<dim3(tiles, tiles + vrows), 256, 0, st>>>(f->Ppred, W, Pout, varout, dp, mp, 0, mp / 8, va);
+    // K5: read-out + deterministic reduction of the per-row partial sums
     k_readout<<<(f->d + 255) / 256, 256, 0, st>>>(mout, varout, record ? f->rec_means : nullptr,
                                                   record ? f->rec_stds : nullptr, nordsieck_scale(f->nu, 0, dt), f->d,
                                                   f->part, f->rec, mp, f->ctr);
@@ -913,11 +887,8 @@ int pnmol_ctx_create(int device, pnmol_ctx** out) {
     if (hipSetDevice(device) != hipSuccess) return -2;
     pnmol_ctx* ctx = new pnmol_ctx();
     ctx->device = device;
-    bool okc = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
-               hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) == hipSuccess;
-    for (auto& e : ctx->ev) okc = okc && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
-    if (!okc) {
-        pnmol_ctx_destroy(ctx);
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
         return -2;
     }
     *out = ctx;
@@ -928,9 +899,6 @@ int pnmol_ctx_destroy(pnmol_ctx* ctx) {
     if (!ctx) return -1;
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
-    if (ctx->side) hipStreamDestroy(ctx->side);
-    for (auto& e : ctx->ev)
-        if (e) hipEventDestroy(e);
     delete ctx;
     return 0;
 }
@@ -1069,7 +1037,6 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
     FCHK(hipMalloc(&f->part, sizeof(double) * 3 * mp));
     FCHK(hipMalloc(&f->ctr, sizeof(int)));
     if (const char* gc = std::getenv("PNMOL_HIP_GRAPH_CHUNK")) f->graph_chunk = std::atoi(gc) / 2 * 2;
-    if (const char* ov = std::getenv("PNMOL_HIP_OVERLAP")) f->overlap = std::atoi(ov) != 0;
     FCHK(hipMalloc(&f->sdiag, sizeof(double) * (mp + 1)));
     FCHK(hipMemcpy(f->ell_col, ecol.data(), sizeof(int) * ecol.size(), hipMemcpyHostToDevice));
     FCHK(hipMemcpy(f->ell_val, eval.data(), sizeof(double) * eval.size(), hipMemcpyHostToDevice));

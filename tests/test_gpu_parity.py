@@ -127,3 +127,76 @@ def test_attempt_step_is_functional(hip_ctx):
     assert np.array_equal(a.y.mean, b.y.mean) and np.array_equal(a.y.cov, b.y.cov)
     c, _ = solver.attempt_step(s0, 2.0 ** -7, pde)      # a different dt from the same state
     assert not np.array_equal(a.y.mean, c.y.mean)
+
+
+@pytest.mark.parametrize("N,K", [(512, 3), (1024, 2)])
+def test_large_mesh_steps(hip_ctx, N, K):
+    """BASELINE headline size (N=512) and config 2 (N=1024), nu=2: a few steps against the oracle
+    (the oracle needs ~1.5 s resp. ~12 s per step at these sizes), then size-independent properties
+    over a longer run: symmetry of the covariance, monotone time grid, finite calibrated diffusion."""
+    dt = 2.0 ** -7
+    pde, solver, opde, osolver = make_pair(N, 2, dt, K)
+    t, means, stds, sig, final = solver.solve_marginals(pde)
+    osol = osolver.solve(opde)
+    omeans, ostds = oracle.read_mean_and_std(osol, osolver.E0)
+    assert np.array_equal(t, osol.t)
+    assert_mean_std_parity(means, stds, omeans, ostds)
+    assert np.all(np.isfinite(sig)) and np.all(sig > 0)
+    if N == 512:
+        cov = final.y.cov
+        np.testing.assert_allclose(cov, cov.T, rtol=0, atol=1e-12 * np.abs(cov).max())
+        var = final.y.marginal_var.reshape(-1, order="F")
+        np.testing.assert_allclose(np.diag(cov), var, rtol=1e-12, atol=0)
+        ocov = osol.cov_sqrtm[-1] @ osol.cov_sqrtm[-1].T
+        np.testing.assert_allclose(cov, ocov, rtol=1e-3, atol=1e-6 * np.abs(ocov).max())
+
+
+def test_two_dimensional_mesh(hip_ctx):
+    """BASELINE config 4's shape at a size the oracle can do: 2-d Dirichlet heat problem (12x12 mesh, 5-point
+    stencils, nu=1).  The reference ships no 2-d recipe; both sides assemble it from the reference's parts."""
+    import pnmol
+
+    dt, K = 2.0 ** -8, 12
+    pde = pnmol.pde.examples.heat_2d_dirichlet_discretized(nums=(12, 12), tmax=K * dt, kernel=pnmol.kernels.SquareExponential())
+    opde = oracle.heat_2d_dirichlet_discretized(nums=(12, 12), tmax=K * dt, kernel=oracle.SquareExponential())
+    for name in ("L", "B", "y0"):
+        np.testing.assert_allclose(getattr(pde, name), getattr(opde, name), rtol=1e-12, atol=1e-14)
+    solver = pnmol.white.LinearWhiteNoiseEK1(num_derivatives=1, steprule=pnmol.odetools.step.Constant(dt),
+                                             spatial_kernel=pnmol.kernels.Matern52() + pnmol.kernels.WhiteNoise())
+    osolver = oracle.WhiteNoiseEK1(num_derivatives=1, steprule=oracle.Constant(dt), canonical_factor_signs=True,
+                                   spatial_kernel=oracle.Matern52() + oracle.WhiteNoise())
+    t, means, stds, sig, _ = solver.solve_marginals(pde)
+    osol = osolver.solve(opde)
+    omeans, ostds = oracle.read_mean_and_std(osol, osolver.E0)
+    assert means.shape == (K + 1, 144)
+    assert_mean_std_parity(means, stds, omeans, ostds)
+
+
+def test_state_roundtrip_and_clone(hip_ctx):
+    """C-ABI state functions: set/get in the reference's F-order, clone, argument checking."""
+    import ctypes
+    from pnmol import _hip
+
+    pde, solver, opde, osolver = make_pair(20, 2, 2.0 ** -6, 2, "neumann")
+    solver.initialize(pde)
+    flt = solver._device_filter
+    rng = np.random.default_rng(0)
+    D = 60
+    A = rng.standard_normal((D, D))
+    cov, mean = A @ A.T, rng.standard_normal((3, 20))
+    st = flt.new_state()
+    st.set(0.25, mean, cov)
+    assert st.t == 0.25
+    np.testing.assert_array_equal(st.mean(), mean)
+    np.testing.assert_array_equal(st.cov(), cov)
+    np.testing.assert_array_equal(st.marginal_var().reshape(-1, order="F"), np.diag(cov))
+    cl = st.clone()
+    np.testing.assert_array_equal(cl.cov(), cov)
+    lib = flt.lib
+    assert lib.pnmol_filter_step(flt.handle, st.handle, 0.1, st.handle, None, None) == -1      # aliasing
+    assert lib.pnmol_filter_step(flt.handle, st.handle, -1.0, cl.handle, None, None) == -1     # dt <= 0
+    assert lib.pnmol_filter_steps(flt.handle, st.handle, 0, 0.1, None, None, None) == -1        # k < 1
+    with pytest.raises(_hip.PnmolHipError):
+        bad = flt.new_state()
+        bad.set(0.0, mean, -cov)                      # a non-PSD covariance must be reported, not swallowed
+        flt.step(bad, 2.0 ** -6)

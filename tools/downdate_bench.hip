@@ -15,16 +15,16 @@ int main() {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int ranges[][2] = {{0, 0}, {0, 8}, {0, 24}, {0, 68}, {24, 68}};
     for (auto& rg : ranges) {
-        for (int rep = 0; rep < 3; ++rep) k_downdate<3><<<dim3(dp / 16, dp / 16), 256>>>(P, W, Po, var, dp, mp, rg[0], rg[1]);
+        for (int rep = 0; rep < 3; ++rep) k_downdate<3><<<dim3(dp / 16, dp / 16), 256>>>(P, W, Po, var, dp, mp, rg[0], rg[1], VecArgs{});
         hipDeviceSynchronize();
         hipEventRecord(e0);
-        for (int rep = 0; rep < 20; ++rep) k_downdate<3><<<dim3(dp / 16, dp / 16), 256>>>(P, W, Po, var, dp, mp, rg[0], rg[1]);
+        for (int rep = 0; rep < 20; ++rep) k_downdate<3><<<dim3(dp / 16, dp / 16), 256>>>(P, W, Po, var, dp, mp, rg[0], rg[1], VecArgs{});
         hipEventRecord(e1); hipDeviceSynchronize();
         float ms; hipEventElapsedTime(&ms, e0, e1);
         std::printf("chunks [%2d,%2d): %.1f us per launch\n", rg[0], rg[1], ms * 1e3 / 20);
     }
     // correctness spot check of the full range against the host
-    k_downdate<3><<<dim3(dp / 16, dp / 16), 256>>>(P, W, Po, var, dp, mp, 0, 68);
+    k_downdate<3><<<dim3(dp / 16, dp / 16), 256>>>(P, W, Po, var, dp, mp, 0, 68, VecArgs{});
     std::vector<double> out(hP.size());
     hipMemcpy(out.data(), Po, sizeof(double) * out.size(), hipMemcpyDeviceToHost);
     double emax = 0;
