@@ -254,6 +254,176 @@ __device__ __forceinline__ void potrf32_inv_wave(double (&v)[NB], int lane, int*
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Two-wave variant of the 32x32 Cholesky + inverse (the one the step uses).
+// Wave 0 factorises: lane (i, h) = (l & 31, l >> 5) holds row i's columns of parity h, u[q] = A[i][2q+h], so one
+// FMA instruction updates two columns.  Column step J: the pivot is already known as a wave-uniform scalar (it was
+// predicted during step J-1 by one scalar FMA), column J is scaled and published to LDS (col[J], permuted so that
+// each half reads its multipliers with ds_read_b128 broadcasts), the next pivot is predicted from two
+// v_readlanes, and the general update reads the row multiplier and the column multipliers back from LDS -- that
+// LDS round trip overlaps the rsqrt chain of the next column instead of sitting in it.
+// Wave 1 builds L^-1 one column behind: it applies the same elementary operations to the identity
+// (Y = X^T, same layout), taking 1/sqrt(pivot) and the column multipliers from LDS once flag[J] is set.
+// Wave 0 never waits for wave 1, so there is no deadlock; each column has its own LDS buffer (no reuse hazard).
+// ------------------------------------------------------------------------------------------
+#ifdef PNMOL_STAMP
+__device__ unsigned long long pnmol_stamp_out[40];
+#define pnmol_stamp pnmol_stamp_out
+#endif
+struct Diag2wLds {
+    double col[NB][64];   // col[J][pi(k)] = L[k][J]  (pi(k) = 16*(k&1) + (k>>1)); [32..63] is a dump area
+    double rs[NB];        // 1/sqrt(pivot J) or 0
+    double piv[NB];       // pivot J
+    int flag[NB];         // column J of `col`/`rs` is published
+};
+
+// value of x held by the 32-lane half HJ, delivered to both halves (v_permlane32_swap: VALU latency, no LDS)
+template <int HJ>
+__device__ __forceinline__ double from_half(double x) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const u2 rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);  // [0]: lanes 0..31 everywhere, [1]: lanes 32..63
+    const u2 rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)rh[HJ], (int)rl[HJ]);
+}
+
+// u[q] -= m * L[2q+h][J] for the columns 2q+h > J of this lane's parity; the multiplier of column J+1 (`bnext`,
+// wave-uniform, only meaningful when HAVE_NEXT) does not go through LDS: it feeds the critical path.
+template <int J, bool HAVE_NEXT>
+__device__ __forceinline__ void diag2w_update(double (&u)[NB / 2], const double* __restrict__ colJ, double nm, int h,
+                                              double bnext) {
+#pragma unroll
+    for (int q = ((J + 1) >> 1) & ~1; q < NB / 2; q += 2) {
+        const double2 b = *reinterpret_cast<const double2*>(colJ + h * 16 + q);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int qq = q + t;
+            const double bv = t ? b.y : b.x;
+            if (2 * qq > J) {  // both parities of this register are right of column J
+                if (HAVE_NEXT && 2 * qq == J + 1) u[qq] = fma(nm, h ? bv : bnext, u[qq]);          // (J odd) k = J+1 on h = 0
+                else if (HAVE_NEXT && 2 * qq + 1 == J + 1) u[qq] = fma(nm, h ? bnext : bv, u[qq]);  // unreachable (2qq > J)
+                else u[qq] = fma(nm, bv, u[qq]);
+            } else if (2 * qq + 1 > J) {  // J == 2 qq: only the odd column 2qq+1 = J+1 is updated
+                u[qq] = h ? fma(nm, HAVE_NEXT ? bnext : bv, u[qq]) : u[qq];
+            }
+        }
+    }
+}
+
+template <int J>
+__device__ __forceinline__ void diag2w_factor_col(double (&u)[NB / 2], double& p, Diag2wLds* L, int lane, int pi_i,
+                                                  double thrv) {
+    constexpr int qJ = J >> 1, hJ = J & 1;
+    const int h = lane >> 5;
+#ifdef PNMOL_STAMP
+    pnmol_stamp[J] = __builtin_amdgcn_s_memtime();
+#endif
+    // Only  rsq -> refine -> (a[J+1][J] * rs) -> fma  is on the pivot-to-pivot chain; everything that does not
+    // need 1/sqrt(p) (pivot test, broadcasts of the still unscaled entries) is issued beside it.
+    const double y0 = __builtin_amdgcn_rsq(p);
+    const bool ok = p > bcast_lane(thrv, J);
+    double an = 0.0, aold = 0.0;
+    if constexpr (J + 1 < NB) {
+        an = bcast_lane(u[qJ], (J + 1) + 32 * hJ);                               // A[J+1][J], unscaled
+        aold = bcast_lane(u[(J + 1) >> 1], (J + 1) + 32 * ((J + 1) & 1));        // A[J+1][J+1]
+    }
+    const double e = fma(-(p * y0), y0, 1.0);
+    const double y = fma(y0 * e, fma(0.375, e, 0.5), y0);
+    const double rs = ok ? y : 0.0;
+    const double pj = p;
+    if constexpr (J + 1 < NB) {
+        const double sj = an * rs;  // = L[J+1][J]
+        p = fma(-sj, sj, aold);     // next pivot (the same FMA the general update performs on that element)
+        const double vj = u[qJ] * rs;
+        const bool own = (h == hJ);
+        u[qJ] = own ? vj : u[qJ];
+        L->col[J][(own ? 0 : 32) + pi_i] = vj;
+        L->rs[J] = rs;  // wave-uniform values: every lane stores the same word (no divergent branch in the stream)
+        L->piv[J] = pj;
+        asm volatile("" ::: "memory");
+        __hip_atomic_store(&L->flag[J], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const double m = from_half<hJ>(vj);  // row multiplier L[i][J] for both halves
+        diag2w_update<J, true>(u, L->col[J], -m, h, sj);
+    } else {
+        const double vj = u[qJ] * rs;
+        u[qJ] = (h == hJ) ? vj : u[qJ];
+        L->rs[J] = rs;
+        L->piv[J] = pj;
+        asm volatile("" ::: "memory");
+        __hip_atomic_store(&L->flag[J], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#pragma unroll
+    for (int q = 0; q < NB / 2; ++q) asm volatile("" : "+v"(u[q]));
+}
+
+template <int J>
+__device__ __forceinline__ void diag2w_inverse_col(double (&u)[NB / 2], Diag2wLds* L, int lane, int pi_c) {
+    constexpr int qJ = J >> 1, hJ = J & 1;
+    const int h = lane >> 5;
+    while (__hip_atomic_load(&L->flag[J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+    const double rs = L->rs[J];
+    const double yj = u[qJ] * rs;
+    const bool own = (h == hJ);
+    u[qJ] = own ? yj : u[qJ];
+    if constexpr (J + 1 < NB) {
+        const double m = from_half<hJ>(yj);
+        diag2w_update<J, false>(u, L->col[J], -m, h, 0.0);
+    }
+#pragma unroll
+    for (int q = 0; q < NB / 2; ++q) asm volatile("" : "+v"(u[q]));
+}
+
+template <int... Js>
+__device__ __forceinline__ void diag2w_factor_all(double (&u)[NB / 2], double& p, Diag2wLds* L, int lane, int pi_i,
+                                                  double thrv, std::integer_sequence<int, Js...>) {
+    (diag2w_factor_col<Js>(u, p, L, lane, pi_i, thrv), ...);
+}
+template <int... Js>
+__device__ __forceinline__ void diag2w_inverse_all(double (&u)[NB / 2], Diag2wLds* L, int lane, int pi_c,
+                                                   std::integer_sequence<int, Js...>) {
+    (diag2w_inverse_col<Js>(u, L, lane, pi_c), ...);
+}
+
+// Called by waves 0 and 1 of a workgroup (wave = 0/1) after T holds the symmetric tile and a __syncthreads() that
+// also covers the zeroing of L->flag.  Writes L (upper zeroed) to Fd (leading dim ld) and L^-1 to Li (32x32).
+__device__ __forceinline__ void diag2w_from_lds(const double* T, double* __restrict__ Fd, long ld,
+                                                double* __restrict__ Li, int wave, int lane, int* info, int base,
+                                                const double* __restrict__ sdiag, double smax, Diag2wLds* L) {
+    const int i = lane & 31, h = lane >> 5;
+    const int pi_i = 16 * (i & 1) + (i >> 1);
+    double u[NB / 2];
+    if (wave == 0) {
+        const double sdv = fabs(sdiag[base + i]);
+        const double thrv = 1e-13 * sdv;
+#pragma unroll
+        for (int q = 0; q < NB / 2; ++q) u[q] = T[i * TLD + 2 * q + h];
+        double p = T[0];
+        diag2w_factor_all(u, p, L, lane, pi_i, thrv, std::make_integer_sequence<int, NB>{});
+#ifdef PNMOL_STAMP
+        pnmol_stamp[32] = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll
+        for (int q = 0; q < NB / 2; ++q) {
+            double2* dst = nullptr;
+            (void)dst;
+            Fd[(long)i * ld + 2 * q + h] = (2 * q + h <= i) ? u[q] : 0.0;
+        }
+        if (lane < NB) {
+            const double pv = L->piv[lane];
+            const bool fatal = !(pv > thrv) && (!(pv == pv) || (pv < -1e-3 * sdv && sdv > 1e-12 * smax));
+            const unsigned long long mk = __ballot(fatal);
+            if (mk != 0 && lane == 0) atomicMin(info, base + __builtin_ctzll(mk));
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < NB / 2; ++q) u[q] = (2 * q + h == i) ? 1.0 : 0.0;
+        diag2w_inverse_all(u, L, lane, pi_i, std::make_integer_sequence<int, NB>{});
+#pragma unroll
+        for (int q = 0; q < NB / 2; ++q) Li[(2 * q + h) * NB + i] = u[q];  // u[q] = Y[i][2q+h] = Linv[2q+h][i]
+    }
+}
+
 // wave 0 of a workgroup factorises the LDS tile T (row stride TLD) and writes L (upper zeroed) to
 // Fd (leading dim ld) and L^-1 to Li (32x32 row-major)
 __device__ __forceinline__ void diag_from_lds(const double* T, double* __restrict__ Fd, long ld,
@@ -311,24 +481,28 @@ __global__ __launch_bounds__(256) void k_front(const double* __restrict__ Ppred,
 }
 
 // first diagonal block: diag(S) -> sdiag, its max -> sdiag[mp]; F[0,0] = chol(G[0,0]), Linv[0] = its inverse
-__global__ __launch_bounds__(64) void k_diag0(const double* __restrict__ G, double* __restrict__ F,
-                                              double* __restrict__ Linv, int ld, int* info_base,
-                                              double* __restrict__ sdiag, const int* __restrict__ ctr) {
+__global__ __launch_bounds__(128) void k_diag0(const double* __restrict__ G, double* __restrict__ F,
+                                               double* __restrict__ Linv, int ld, int* info_base,
+                                               double* __restrict__ sdiag, const int* __restrict__ ctr) {
     __shared__ double sT[NB * TLD];
-    __shared__ __attribute__((aligned(16))) double colbuf[128];
-    const int lane = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) Diag2wLds dl;
+    __shared__ double smx[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double smax = 0.0;
-    for (int e = lane; e < ld; e += 64) {
+    for (int e = tid; e < ld; e += 128) {
         const double x = G[(long)e * ld + e];
         sdiag[e] = x;
         smax = fmax(smax, fabs(x));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) smax = fmax(smax, __shfl_xor(smax, o));
-    if (lane == 0) sdiag[ld] = smax;
-    for (int e = lane; e < NB * NB; e += 64) sT[(e >> 5) * TLD + (e & 31)] = G[(long)(e >> 5) * ld + (e & 31)];
+    if (lane == 0) smx[wave] = smax;
+    if (tid < NB) dl.flag[tid] = 0;
+    for (int e = tid; e < NB * NB; e += 128) sT[(e >> 5) * TLD + (e & 31)] = G[(long)(e >> 5) * ld + (e & 31)];
     __syncthreads();
-    diag_from_lds(sT, F, ld, Linv, lane, info_base + (*ctr - 1), 0, sdiag, smax, colbuf);
+    smax = fmax(smx[0], smx[1]);
+    if (tid == 0) sdiag[ld] = smax;
+    diag2w_from_lds(sT, F, ld, Linv, wave, lane, info_base + (*ctr - 1), 0, sdiag, smax, &dl);
 }
 
 // panel j:  L_Ij = G_Ij Linv_j^T  for all row blocks I > j  (written to F by the c == 0 column),
@@ -339,7 +513,9 @@ __global__ __launch_bounds__(256) void k_panel(double* __restrict__ G, double* _
                                                int* info_base, const double* __restrict__ sdiag,
                                                const int* __restrict__ ctr) {
     __shared__ __attribute__((aligned(16))) double sA[NB * TLD], sB[NB * TLD], sI[NB * TLD];
+    __shared__ __attribute__((aligned(16))) Diag2wLds dl;
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+    if (tid < NB) dl.flag[tid] = 0;
     const int I = j + 1 + blockIdx.x;
     const int c = blockIdx.y;
     const int Kc = j + 1 + c;
@@ -392,9 +568,9 @@ __global__ __launch_bounds__(256) void k_panel(double* __restrict__ G, double* _
 #pragma unroll
     for (int r = 0; r < 4; ++r) sA[(wr * 16 + fk + 4 * r) * TLD + wc * 16 + fr] = acc[r];
     __syncthreads();
-    if (w == 0)
-        diag_from_lds(sA, F + ((long)(j + 1) * NB) * ld + (long)(j + 1) * NB, ld, Linv + (long)(j + 1) * NB * NB, l,
-                      info_base + (*ctr - 1), (j + 1) * NB, sdiag, sdiag[ld], sI /* free by now */);
+    if (w < 2)  // waves 0 and 1: factor / inverse (two-wave scheme above)
+        diag2w_from_lds(sA, F + ((long)(j + 1) * NB) * ld + (long)(j + 1) * NB, ld, Linv + (long)(j + 1) * NB * NB, w, l,
+                        info_base + (*ctr - 1), (j + 1) * NB, sdiag, sdiag[ld], &dl);
 }
 
 // One wave per row of four matrix-vector products that all need the finished sweep (role of the extra
@@ -738,7 +914,7 @@ int launch_step(pnmol_filter* f, const double* Pin, const double* min, double fr
         Pin, f->Ppred, f->Kg, c, dp, min, f->mpred, f->shift, f->G, f->zbuf, mm, f->ctr);
     // K2: G = [S; P-H^T; z; I] and the first diagonal block
     k_front<<<dim3((mp + 255) / 256, (unsigned)(Dp + 2 * mp)), 256, 0, st>>>(f->Ppred, f->G, f->rdiag, f->Rdense, mm, Dp);
-    k_diag0<<<1, 64, 0, st>>>(f->G, f->F, f->Linv, mp, f->info, f->sdiag, f->ctr);
+    k_diag0<<<1, 128, 0, st>>>(f->G, f->F, f->Linv, mp, f->info, f->sdiag, f->ctr);
     // K3: right-looking sweep, one launch per 32-column panel
     for (int j = 0; j < f->CB; ++j) {
         const int nrb = f->RT - (j + 1);
