@@ -55,6 +55,28 @@ struct MeasModel {
     double c0, c1;
 };
 
+// Row i of H as (index, coefficient) pairs: slot 0 is the derivative-1 entry c1 at (1,i) (PDE rows only), slots
+// 1..w the ELL stencil entries c0 * Hv[i,e] at (0, col).  Loaded once per thread so that the dot products below
+// issue independent loads (the loops are unrolled in groups of four; absent entries get coefficient 0 / index 0).
+constexpr int HW = 4;  // fast-path stencil width; wider rows (dense Jacobians) use the generic loops
+
+struct HRow {
+    int idx[HW + 1];
+    double cf[HW + 1];
+};
+
+__device__ __forceinline__ void h_row_load(const MeasModel& mm, int i, HRow& r) {
+    r.idx[0] = (i < mm.d) ? mm.dp + i : 0;
+    r.cf[0] = (i < mm.d) ? mm.c1 : 0.0;
+#pragma unroll
+    for (int e = 0; e < HW; ++e) {
+        const int cidx = (e < mm.w) ? mm.ell_col[e * mm.mp + i] : -1;
+        const double val = (e < mm.w) ? mm.ell_val[e * mm.mp + i] : 0.0;
+        r.idx[e + 1] = cidx >= 0 ? cidx : 0;
+        r.cf[e + 1] = cidx >= 0 ? mm.c0 * val : 0.0;
+    }
+}
+
 // (H x)[i] for a state-indexed vector x (global or LDS)
 __device__ __forceinline__ double h_row_dot(const MeasModel& mm, int i, const double* x) {
     double v = 0.0;
@@ -63,6 +85,18 @@ __device__ __forceinline__ double h_row_dot(const MeasModel& mm, int i, const do
         const int cidx = mm.ell_col[e * mm.mp + i];
         if (cidx >= 0) v += mm.c0 * mm.ell_val[e * mm.mp + i] * x[cidx];
     }
+    return v;
+}
+
+// same value (same summation order: derivative-1 term first, then the stencil entries) from a preloaded row
+template <int W>
+__device__ __forceinline__ double h_row_dot_w(const HRow& r, const double* __restrict__ x) {
+    double xv[W + 1];
+#pragma unroll
+    for (int e = 0; e <= W; ++e) xv[e] = x[r.idx[e]];
+    double v = r.cf[0] * xv[0];
+#pragma unroll
+    for (int e = 1; e <= W; ++e) v += r.cf[e] * xv[e];
     return v;
 }
 
@@ -145,6 +179,23 @@ __device__ __forceinline__ double s_entry(const double* __restrict__ Ppred, long
         const int cidx = mm.ell_col[e * mm.mp + ip];
         if (cidx >= 0) v += mm.c0 * mm.ell_val[e * mm.mp + ip] * h_row_dot(mm, i, Ppred + (long)cidx * Dp);
     }
+    if (ip == i) v += rdiag[i];
+    if (Rdense) v += Rdense[(long)ip * mm.mp + i];
+    return v;
+}
+
+// stencil width <= W: all index loads, then all P- loads, are independent (pipelined) instead of 16 dependent gathers
+template <int W>
+__device__ __forceinline__ double s_entry_w(const double* __restrict__ Ppred, long Dp, const MeasModel& mm,
+                                            const HRow& rrow /* row ip */, const HRow& rcol /* row i */, int ip, int i,
+                                            const double* __restrict__ rdiag, const double* __restrict__ Rdense) {
+    if (ip >= mm.m || i >= mm.m) return (ip == i) ? 1.0 : 0.0;
+    double t[W + 1];
+#pragma unroll
+    for (int e = 0; e <= W; ++e) t[e] = h_row_dot_w<W>(rcol, Ppred + (long)rrow.idx[e] * Dp);
+    double v = rrow.cf[0] * t[0];
+#pragma unroll
+    for (int e = 1; e <= W; ++e) v += rrow.cf[e] * t[e];
     if (ip == i) v += rdiag[i];
     if (Rdense) v += Rdense[(long)ip * mm.mp + i];
     return v;
@@ -352,8 +403,10 @@ __device__ __forceinline__ void diag2w_factor_col(double (&u)[NB / 2], double& p
         asm volatile("" ::: "memory");
         __hip_atomic_store(&L->flag[J], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+#ifndef PNMOL_NO_COLBARRIER
 #pragma unroll
     for (int q = 0; q < NB / 2; ++q) asm volatile("" : "+v"(u[q]));
+#endif
 }
 
 template <int J>
@@ -370,8 +423,10 @@ __device__ __forceinline__ void diag2w_inverse_col(double (&u)[NB / 2], Diag2wLd
         const double m = from_half<hJ>(yj);
         diag2w_update<J, false>(u, L->col[J], -m, h, 0.0);
     }
+#ifndef PNMOL_NO_COLBARRIER
 #pragma unroll
     for (int q = 0; q < NB / 2; ++q) asm volatile("" : "+v"(u[q]));
+#endif
 }
 
 template <int... Js>
@@ -468,12 +523,37 @@ __global__ __launch_bounds__(256) void k_front(const double* __restrict__ Ppred,
     const int i = blockIdx.x * 256 + tid;
     const long y = blockIdx.y;
     const int mp = mm.mp;
+    const bool narrow = mm.w <= HW;
     if (y < Dp) {
-        if (i < mp) G[((long)mp + y) * mp + i] = (i < mm.m) ? h_row_dot(mm, i, Ppred + y * Dp) : 0.0;
+        if (i < mp) {
+            double v = 0.0;
+            if (i < mm.m) {
+                if (narrow) {
+                    HRow rc;
+                    h_row_load(mm, i, rc);
+                    v = h_row_dot_w<HW>(rc, Ppred + y * Dp);
+                } else {
+                    v = h_row_dot(mm, i, Ppred + y * Dp);
+                }
+            }
+            G[((long)mp + y) * mp + i] = v;
+        }
         return;
     }
     if (y < Dp + mp) {
-        if (i < mp) G[(y - Dp) * mp + i] = s_entry(Ppred, Dp, mm, (int)(y - Dp), i, rdiag, Rdense);
+        const int ip = (int)(y - Dp);
+        if (i < mp) {
+            double v;
+            if (narrow && ip < mm.m && i < mm.m) {
+                HRow rr, rc;
+                h_row_load(mm, ip, rr);
+                h_row_load(mm, i, rc);
+                v = s_entry_w<HW>(Ppred, Dp, mm, rr, rc, ip, i, rdiag, Rdense);
+            } else {
+                v = s_entry(Ppred, Dp, mm, ip, i, rdiag, Rdense);
+            }
+            G[(long)ip * mp + i] = v;
+        }
         return;
     }
     const long q = y - Dp - mp;
