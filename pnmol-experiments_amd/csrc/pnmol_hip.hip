@@ -322,7 +322,8 @@ __device__ unsigned long long pnmol_stamp_out[40];
 #define pnmol_stamp pnmol_stamp_out
 #endif
 struct Diag2wLds {
-    double col[NB][64];   // col[J][pi(k)] = L[k][J]  (pi(k) = 16*(k&1) + (k>>1)); [32..63] is a dump area
+    double col[NB][NB];   // col[J][pi(k)] = L[k][J]  (pi(k) = 16*(k&1) + (k>>1))
+    double dump[NB];      // where the half that does not own column J writes (keeps the stream branch-free)
     double rs[NB];        // 1/sqrt(pivot J) or 0
     double piv[NB];       // pivot J
     int flag[NB];         // column J of `col`/`rs` is published
@@ -388,7 +389,7 @@ __device__ __forceinline__ void diag2w_factor_col(double (&u)[NB / 2], double& p
         const double vj = u[qJ] * rs;
         const bool own = (h == hJ);
         u[qJ] = own ? vj : u[qJ];
-        L->col[J][(own ? 0 : 32) + pi_i] = vj;
+        (own ? &L->col[J][0] : &L->dump[0])[pi_i] = vj;
         L->rs[J] = rs;  // wave-uniform values: every lane stores the same word (no divergent branch in the stream)
         L->piv[J] = pj;
         asm volatile("" ::: "memory");
@@ -592,10 +593,15 @@ __global__ __launch_bounds__(256) void k_panel(double* __restrict__ G, double* _
                                                double* __restrict__ Linv, int ld, int j, int CB, int RBS,
                                                int* info_base, const double* __restrict__ sdiag,
                                                const int* __restrict__ ctr) {
-    __shared__ __attribute__((aligned(16))) double sA[NB * TLD], sB[NB * TLD], sI[NB * TLD];
-    __shared__ __attribute__((aligned(16))) Diag2wLds dl;
+    // +2200 doubles of padding: A/B on one MI355X shows the latency-bound diagonal waves run ~2 % faster with at most
+    // three of these workgroups per CU (42.9 KB each) than with six (25 KB)
+    __shared__ __attribute__((aligned(16))) double smem_p[3 * NB * TLD + 2200];
+    double* sA = smem_p;
+    double* sB = smem_p + NB * TLD;
+    double* sI = smem_p + 2 * NB * TLD;
+    static_assert(sizeof(Diag2wLds) <= 2 * NB * TLD * sizeof(double), "Diag2wLds must fit in sB + sI");
+    Diag2wLds* dlp = reinterpret_cast<Diag2wLds*>(sB);  // sB and sI are free once the diagonal tile sits in sA
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
-    if (tid < NB) dl.flag[tid] = 0;
     const int I = j + 1 + blockIdx.x;
     const int c = blockIdx.y;
     const int Kc = j + 1 + c;
@@ -647,10 +653,11 @@ __global__ __launch_bounds__(256) void k_panel(double* __restrict__ G, double* _
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 4; ++r) sA[(wr * 16 + fk + 4 * r) * TLD + wc * 16 + fr] = acc[r];
+    if (tid < NB) dlp->flag[tid] = 0;
     __syncthreads();
     if (w < 2)  // waves 0 and 1: factor / inverse (two-wave scheme above)
         diag2w_from_lds(sA, F + ((long)(j + 1) * NB) * ld + (long)(j + 1) * NB, ld, Linv + (long)(j + 1) * NB * NB, w, l,
-                        info_base + (*ctr - 1), (j + 1) * NB, sdiag, sdiag[ld], &dl);
+                        info_base + (*ctr - 1), (j + 1) * NB, sdiag, sdiag[ld], dlp);
 }
 
 // One wave per row of four matrix-vector products that all need the finished sweep (role of the extra

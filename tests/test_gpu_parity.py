@@ -200,3 +200,29 @@ def test_state_roundtrip_and_clone(hip_ctx):
         bad = flt.new_state()
         bad.set(0.0, mean, -cov)                      # a non-PSD covariance must be reported, not swallowed
         flt.step(bad, 2.0 ** -6)
+
+
+def test_full_size_2d_mesh_properties(hip_ctx):
+    """BASELINE config 5's mesh (64x64 Dirichlet heat problem, nu=1: D=8192, m=4348) in fp64.  The oracle needs
+    minutes per step at this size, so only size-independent properties are checked: finite, symmetric PSD-diagonal
+    covariance, boundary nodes pinned, mean decaying like the analytic heat mode, determinism of a repeated run."""
+    import pnmol
+
+    dt, K, kappa = 2.0 ** -9, 3, 0.05
+    pde = pnmol.pde.examples.heat_2d_dirichlet_discretized(nums=(64, 64), tmax=K * dt, diffusion_rate=kappa,
+                                                           kernel=pnmol.kernels.SquareExponential())
+    solver = pnmol.white.LinearWhiteNoiseEK1(num_derivatives=1, steprule=pnmol.odetools.step.Constant(dt),
+                                             spatial_kernel=pnmol.kernels.Matern52() + pnmol.kernels.WhiteNoise())
+    t, means, stds, sig, final = solver.solve_marginals(pde)
+    assert means.shape == (K + 1, 4096) and np.all(np.isfinite(means)) and np.all(np.isfinite(stds))
+    assert np.all(np.isfinite(sig)) and np.all(sig > 0)
+    on_boundary = pde.mesh_spatial.boundary[1]
+    assert np.abs(means[-1][on_boundary]).max() < 1e-8
+    assert stds[-1][on_boundary].max() < 1e-4 * stds[-1].max()
+    # y0 = 0.1 sin(pi x) sin(pi y) is an eigenmode: u(t) = exp(-2 kappa pi^2 t) y0 up to the FD error
+    expected = np.exp(-2 * kappa * np.pi ** 2 * t[-1]) * pde.y0
+    np.testing.assert_allclose(means[-1], expected, rtol=0, atol=2e-3 * np.abs(pde.y0).max())
+    var = final.y.marginal_var
+    assert var.min() > -1e-9 * var.max()
+    t2, means2, stds2, sig2, _ = solver.solve_marginals(pde)
+    assert np.array_equal(means, means2) and np.array_equal(stds, stds2) and np.array_equal(sig, sig2)
