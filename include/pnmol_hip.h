@@ -64,6 +64,15 @@ int pnmol_filter_destroy(pnmol_filter* f);
 int pnmol_filter_set_error_model(pnmol_filter* f, double dt, const double* Sq_inv,
                                  const double* Sq_diag);
 
+/* Semilinear EK1 (`SemiLinearWhiteNoiseEK1.evaluate_ode`, white.py:189-208): the measurement rows become
+ * H_ode = E1 - (J_x + L) E0 with shift b = J_x m_at - f(t, m_at), re-linearised at every step.
+ * `pnmol_filter_predict_mean` returns m_at = E0 P m^- (predicted derivative-0 mean, raw coordinates) for a step
+ * of size dt from `in`; the caller evaluates f and df there and passes M = J_x + L (d,d) and shift (d) to
+ * `pnmol_filter_set_operator` (NULL shift = zeros), which replaces the stencil rows used by the following
+ * `pnmol_filter_step(s)` calls.  The boundary rows B are kept. */
+int pnmol_filter_predict_mean(pnmol_filter* f, const pnmol_state* in, double dt, double* m_at_d);
+int pnmol_filter_set_operator(pnmol_filter* f, const double* M_dd, const double* shift_d);
+
 /* states ----------------------------------------------------------------------------- */
 int pnmol_state_create(pnmol_filter* f, pnmol_state** out);
 int pnmol_state_destroy(pnmol_state* s);

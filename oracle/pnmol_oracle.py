@@ -366,6 +366,18 @@ def heat_1d_discretized(*, bbox=None, dx=0.05, stencil_size_interior=3, stencil_
                        bbox=bbox, diffop_scale=diffusion_rate, bcond=bcond, f=None, df=None)
 
 
+def spruce_budworm_1d_discretized(*, bbox=None, t0=0.0, tmax=10.0, diffusion_rate=1.0, dx=0.1, kernel=None,
+                                  stencil_size_interior=3, stencil_size_boundary=3, bcond="dirichlet", growth_rate=1.0):
+    """examples.py:251-341: Fisher's equation u_t = kappa u_xx + c u (1 - u); y0 = 0.1 sin(pi x)."""
+    p = heat_1d_discretized(bbox=bbox, dx=dx, stencil_size_interior=stencil_size_interior,
+                            stencil_size_boundary=stencil_size_boundary, t0=t0, tmax=tmax,
+                            y0_fun=lambda x: 0.1 * np.sin(np.pi * x), diffusion_rate=diffusion_rate, kernel=kernel,
+                            bcond=bcond)
+    p.f = lambda _t, x: growth_rate * x * (1.0 - x)
+    p.df = lambda _t, x: np.diag(growth_rate * (1.0 - 2.0 * x))
+    return p
+
+
 def heat_2d_dirichlet_discretized(*, nums=(8, 8), stencil_size_interior=5, stencil_size_boundary=5,
                                   t0=0.0, tmax=1.0, diffusion_rate=0.05, kernel=None):
     """Build-side construction of BASELINE config 5 from reference parts

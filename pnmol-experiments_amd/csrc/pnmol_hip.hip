@@ -947,6 +947,8 @@ struct pnmol_filter {
     int* info = nullptr;
     std::vector<double> sqdiag;
     double sq_dt = -1.0;
+    std::vector<double> hB;   // host copy of pde.B (nB x d) for operator rebuilds
+    int ell_cap = 0;          // allocated ELL width
     // scratch state for ping-pong inside steps()
     double *tmpP = nullptr, *tmpMean = nullptr;
     double *rec_means = nullptr, *rec_stds = nullptr;
@@ -1082,6 +1084,32 @@ int get_graph(pnmol_filter* f, double* P0, double* M0, double* P1, double* M1, d
     return 0;
 }
 
+// ELL image of Hv = [-M; B] (rows padded to mp, arrays [e*mp + i]); returns the width
+int build_ell(const double* M, const double* B, int d, int nB, int mp, std::vector<int>& ecol, std::vector<double>& eval) {
+    const int m = d + nB;
+    int w = 1;
+    for (int i = 0; i < m; ++i) {
+        int c = 0;
+        const double* row = i < d ? M + (long)i * d : B + (long)(i - d) * d;
+        for (int k = 0; k < d; ++k) c += row[k] != 0.0;
+        w = c > w ? c : w;
+    }
+    ecol.assign((size_t)w * mp, -1);
+    eval.assign((size_t)w * mp, 0.0);
+    for (int i = 0; i < m; ++i) {
+        int e = 0;
+        for (int k = 0; k < d; ++k) {
+            const double v = i < d ? -M[(long)i * d + k] : B[(long)(i - d) * d + k];
+            if (v != 0.0) {
+                ecol[(size_t)e * mp + i] = k;  // state index (0, k) = k
+                eval[(size_t)e * mp + i] = v;
+                ++e;
+            }
+        }
+    }
+    return w;
+}
+
 // graphs for `k` constant-dt steps from state `s` (host work: capture + instantiate, cached)
 int prepare_graphs(pnmol_filter* f, pnmol_state* s, int k, double dt, hipGraphExec_t* gbig, hipGraphExec_t* gpair) {
     *gbig = *gpair = nullptr;
@@ -1207,27 +1235,12 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
         }
 
     // Hv = [-L; B] in ELL, rows padded to mp
-    std::vector<int> nnz(m, 0);
-    for (int i = 0; i < d; ++i)
-        for (int k = 0; k < d; ++k) nnz[i] += desc->L[(long)i * d + k] != 0.0;
-    for (int r = 0; r < nB; ++r)
-        for (int k = 0; k < d; ++k) nnz[d + r] += desc->B[(long)r * d + k] != 0.0;
-    int w = 1;
-    for (int i = 0; i < m; ++i) w = nnz[i] > w ? nnz[i] : w;
+    std::vector<int> ecol;
+    std::vector<double> eval;
+    f->hB.assign(desc->B ? desc->B : nullptr, desc->B ? desc->B + (size_t)nB * d : nullptr);
+    const int w = build_ell(desc->L, f->hB.data(), d, nB, mp, ecol, eval);
     f->ellw = w;
-    std::vector<int> ecol((size_t)w * mp, -1);
-    std::vector<double> eval((size_t)w * mp, 0.0);
-    for (int i = 0; i < m; ++i) {
-        int e = 0;
-        for (int k = 0; k < d; ++k) {
-            const double v = i < d ? -desc->L[(long)i * d + k] : desc->B[(long)(i - d) * d + k];
-            if (v != 0.0) {
-                ecol[(size_t)e * mp + i] = k;  // state index (0, k) = k
-                eval[(size_t)e * mp + i] = v;
-                ++e;
-            }
-        }
-    }
+    f->ell_cap = w;
     // R = blockdiag(E E^T, Rb Rb^T): diagonal fast path, dense otherwise
     bool diag = true;
     for (int i = 0; i < d && diag; ++i)
@@ -1363,6 +1376,52 @@ int pnmol_filter_set_error_model(pnmol_filter* f, double dt, const double* Sq_in
     f->sqdiag.assign(Sq_diag, Sq_diag + m);
     f->sq_dt = dt;
     drop_graphs(f);
+    return 0;
+}
+
+int pnmol_filter_set_operator(pnmol_filter* f, const double* M_dd, const double* shift_d) {
+    if (!f || !M_dd) return -1;
+    pnmol_ctx* ctx = f->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::vector<int> ecol;
+    std::vector<double> eval;
+    const int w = build_ell(M_dd, f->hB.data(), f->d, f->nB, f->mp, ecol, eval);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    drop_graphs(f);  // the stencil width / pointers are baked into captured launches
+    if (w > f->ell_cap) {
+        if (f->ell_col) (void)hipFree(f->ell_col);
+        if (f->ell_val) (void)hipFree(f->ell_val);
+        f->ell_col = nullptr, f->ell_val = nullptr, f->ell_cap = 0;
+        HIPCHK(ctx, hipMalloc(&f->ell_col, sizeof(int) * ecol.size()));
+        HIPCHK(ctx, hipMalloc(&f->ell_val, sizeof(double) * eval.size()));
+        f->ell_cap = w;
+    }
+    f->ellw = w;
+    HIPCHK(ctx, hipMemcpy(f->ell_col, ecol.data(), sizeof(int) * ecol.size(), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(f->ell_val, eval.data(), sizeof(double) * eval.size(), hipMemcpyHostToDevice));
+    std::vector<double> sh((size_t)f->mp, 0.0);
+    if (shift_d) std::memcpy(sh.data(), shift_d, sizeof(double) * f->d);
+    HIPCHK(ctx, hipMemcpy(f->shift, sh.data(), sizeof(double) * sh.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int pnmol_filter_predict_mean(pnmol_filter* f, const pnmol_state* in, double dt, double* m_at_d) {
+    if (!f || !in || in->f != f || !m_at_d || !(dt > 0.0)) return -1;
+    pnmol_ctx* ctx = f->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::vector<double> hm((size_t)f->Dp);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(hm.data(), in->mean, sizeof(double) * hm.size(), hipMemcpyDeviceToHost));
+    // m^- = A m in the Nordsieck frame of dt (white.py:104-107); row 0 of A1, then back to raw coordinates
+    const double s0 = nordsieck_scale(f->nu, 0, dt);
+    for (int j = 0; j < f->d; ++j) {
+        double acc = 0.0;
+        for (int a = 0; a < f->n; ++a) {
+            const double so = in->frame_dt == 0.0 ? 1.0 : nordsieck_scale(f->nu, a, in->frame_dt);
+            acc += f->iwp.A1[a] * (so / nordsieck_scale(f->nu, a, dt)) * hm[(size_t)a * f->dp + j];
+        }
+        m_at_d[j] = s0 * acc;
+    }
     return 0;
 }
 

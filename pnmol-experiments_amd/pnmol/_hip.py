@@ -53,6 +53,8 @@ SYMBOLS = {
     "pnmol_filter_create": (ctypes.c_int, [_vp, ctypes.POINTER(FilterDesc), ctypes.POINTER(_vp)]),
     "pnmol_filter_destroy": (ctypes.c_int, [_vp]),
     "pnmol_filter_set_error_model": (ctypes.c_int, [_vp, ctypes.c_double, _c_double_p, _c_double_p]),
+    "pnmol_filter_predict_mean": (ctypes.c_int, [_vp, _vp, ctypes.c_double, _c_double_p]),
+    "pnmol_filter_set_operator": (ctypes.c_int, [_vp, _c_double_p, _c_double_p]),
     "pnmol_state_create": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
     "pnmol_state_destroy": (ctypes.c_int, [_vp]),
     "pnmol_state_clone": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
@@ -173,6 +175,19 @@ class Filter:
 
     def new_state(self):
         return State(self)
+
+    def predict_mean(self, state_in, dt):
+        out = np.empty(self.d)
+        self.ctx.check(self.lib.pnmol_filter_predict_mean(self.handle, state_in.handle, float(dt), _dp(out)),
+                       "pnmol_filter_predict_mean")
+        return out
+
+    def set_operator(self, M, shift=None):
+        a = _f64(M, (self.d, self.d))
+        b = _f64(shift, (self.d,)) if shift is not None else None
+        self.ctx.check(self.lib.pnmol_filter_set_operator(self.handle, _dp(a), _dp(b) if b is not None else None),
+                       "pnmol_filter_set_operator")
+        self.error_model_dt = None
 
     def step(self, state_in, dt, want_error=True):
         out = State(self)

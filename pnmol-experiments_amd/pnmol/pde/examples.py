@@ -1,7 +1,7 @@
 """Problem recipes (reference: src/pnmol/pde/examples.py:13-81, :347-357).
 
-Heat equation recipes only; SIR / Lotka-Volterra / spruce-budworm belong to the semilinear
-"next" row of the scope table.
+Heat equation and spruce-budworm (Fisher) recipes; the SIR / Lotka-Volterra systems of PDEs are out of scope
+(SURVEY.md section 2, row 11).
 """
 
 import functools
@@ -51,6 +51,42 @@ def heat_2d_dirichlet_discretized(*, nums=(64, 64), stencil_size_interior=5, ste
                     kernel=kernel or kernels.SquareExponential(), stencil_size_interior=stencil_size_interior,
                     stencil_size_boundary=stencil_size_boundary)
     return heat
+
+
+def spruce_budworm_1d_discretized(*, bbox=None, t0=0.0, tmax=10.0, diffusion_rate=1.0, y0_fun=None, dx=0.1, kernel=None,
+                                  nugget_gram_matrix_fd=0.0, stencil_size_interior=3, stencil_size_boundary=3,
+                                  bcond="dirichlet", growth_rate=1.0):
+    """examples.py:251-289."""
+    spruce = spruce_budworm_1d(bbox=bbox, t0=t0, tmax=tmax, diffusion_rate=diffusion_rate, y0_fun=y0_fun, bcond=bcond,
+                               growth_rate=growth_rate)
+    mesh_spatial = mesh.RectangularMesh.from_bbox_1d(spruce.bbox, step=dx)
+    if kernel is None:
+        kernel = kernels.SquareExponential()
+    spruce.discretize(mesh_spatial=mesh_spatial, kernel=kernel, stencil_size_interior=stencil_size_interior,
+                      stencil_size_boundary=stencil_size_boundary, nugget_gram_matrix=nugget_gram_matrix_fd)
+    return spruce
+
+
+def spruce_budworm_1d(*, bbox=None, t0=0.0, tmax=10.0, diffusion_rate=0.1, y0_fun=None, bcond="dirichlet",
+                      growth_rate=1.0):
+    """Fisher's equation u_t = kappa u_xx + c u (1 - u)  (examples.py:292-341); df is the (diagonal) Jacobian."""
+    if bbox is None:
+        bbox = [0.0, 1.0]
+    bbox = np.asarray(bbox, dtype=np.float64)
+    if y0_fun is None:
+        y0_fun = sin_bell_1d
+
+    def f_spruce(_, x, c=growth_rate):
+        return c * x * (1.0 - x)
+
+    def df_spruce(_, x, c=growth_rate):
+        return np.diag(c * (1.0 - 2.0 * np.asarray(x)))
+
+    cls = {"dirichlet": problems.SemiLinearEvolutionDirichlet, "neumann": problems.SemiLinearEvolutionNeumann}.get(bcond)
+    if cls is None:
+        raise ValueError
+    return cls(t0=t0, tmax=tmax, y0_fun=y0_fun, bbox=bbox, diffop=diffops.laplace(), diffop_scale=diffusion_rate,
+               f=f_spruce, df=df_spruce, df_diagonal=None)
 
 
 # Initial-condition defaults; they adhere to Dirichlet conditions (examples.py:344-357)

@@ -39,15 +39,11 @@ class _WhiteNoiseEK1Base(pdefilter.PDEFilter):
 
     def _bind(self, pde, gamma):
         ctx = _hip.Context.default()
-        self._device_filter = _hip.Filter(ctx, L=self._jacobian_plus_L(pde), B=pde.B, E_sqrtm=pde.E_sqrtm,
-                                          R_sqrtm=pde.R_sqrtm, Gamma=gamma, num_derivatives=self.num_derivatives)
+        self._device_filter = _hip.Filter(ctx, L=pde.L, B=pde.B, E_sqrtm=pde.E_sqrtm, R_sqrtm=pde.R_sqrtm, Gamma=gamma,
+                                          num_derivatives=self.num_derivatives)
         self._device_pde = pde
         self._gram = gamma @ gamma.T
         self._error_models = {}
-
-    @staticmethod
-    def _jacobian_plus_L(pde):
-        return pde.L
 
     def initialize(self, pde):
         """Initial state: prior conditioned on y0 and on the PDE/BC residual at t0 (white.py:12-80).
@@ -110,15 +106,18 @@ class _WhiteNoiseEK1Base(pdefilter.PDEFilter):
         return mean, blocks
 
     # ------------------------------------------------------------------ step-invariant error model
-    def _error_model(self, pde, dt):
-        """Sq^-1 and diag(Sq) of `estimate_error` (white.py:153-162) in the Nordsieck frame of dt."""
+    def _error_model(self, pde, dt, M=None):
+        """Sq^-1 and diag(Sq) of `estimate_error` (white.py:153-162) in the Nordsieck frame of dt.
+        `M` is the operator of the linearisation (L for linear problems: cached per dt; J_x + L otherwise)."""
         key = float(dt)
-        if self._error_models is None or key not in self._error_models:
+        cache = M is None
+        M = pde.L if M is None else M
+        if not cache or self._error_models is None or key not in self._error_models:
             d, nB = pde.L.shape[0], pde.B.shape[0]
             s, _ = self.iwp.nordsieck_preconditioner_1d_raw(dt)
             n = self.num_derivatives + 1
             Q1 = np.flip(scipy.linalg.hilbert(n))
-            Hv = scipy.sparse.csr_matrix(np.vstack((-self._jacobian_plus_L(pde), pde.B)))
+            Hv = scipy.sparse.csr_matrix(np.vstack((-M, pde.B)))
             F1K = np.vstack((self._gram, np.zeros((nB, d))))    # [I;0] K
             HvK = Hv @ self._gram
             cross = (Hv @ F1K.T).T                              # F1 K Hv^T
@@ -128,7 +127,10 @@ class _WhiteNoiseEK1Base(pdefilter.PDEFilter):
             Sq = Sq + Ebc @ Ebc.T
             Sq = 0.5 * (Sq + Sq.T)
             inv = scipy.linalg.cho_solve(scipy.linalg.cho_factor(Sq, lower=True), np.eye(d + nB))
-            self._error_models = {key: (0.5 * (inv + inv.T), np.diag(Sq).copy())}
+            model = (0.5 * (inv + inv.T), np.diag(Sq).copy())
+            if not cache:
+                return model
+            self._error_models = {key: model}
         return self._error_models[key]
 
     def _ensure_error_model(self, pde, dt):
@@ -147,10 +149,21 @@ class _WhiteNoiseEK1Base(pdefilter.PDEFilter):
         dev.set(state.t, np.asarray(y.mean), C @ C.T)
         return dev
 
+    semilinear = False
+
     def attempt_step(self, state, dt, pde):
         """One predict + update + calibrate step on the GPU (white.py:96-146); `state` is not modified."""
         dev_in = self._device_state_of(state, pde)
-        self._ensure_error_model(pde, dt)
+        if self.semilinear:
+            # EK1 linearisation at the predicted mean (white.py:192-208): f and df are host callables, so the
+            # predicted point comes back once per step; the new stencil rows and shift go to the device
+            flt = self._device_filter
+            m_at = flt.predict_mean(dev_in, dt)
+            M, shift = self._linearize(pde, m_at, state.t + dt)
+            flt.set_operator(M, shift)
+            flt.set_error_model(dt, *self._error_model(pde, dt, M=M))
+        else:
+            self._ensure_error_model(pde, dt)
         dev_out, info, error = self._device_filter.step(dev_in, dt)
         self.last_step_info = info
         m_new = dev_out.mean()
@@ -207,11 +220,16 @@ class LinearWhiteNoiseEK1(_WhiteNoiseEK1Base):
 
 
 class SemiLinearWhiteNoiseEK1(_WhiteNoiseEK1Base):
-    """EK1 for semilinear PDEs (white.py:189-208).  Scope row f2 ("next"): not built yet."""
+    """EK1 for semilinear PDEs u_t = L u + f(t, u) (white.py:189-208): H = [E1 - (J_x + L) E0 ; B E0] and
+    z = H m + [J_x m_at - f(t, m_at); 0], re-linearised at the predicted mean of every step."""
+
+    semilinear = True
 
     @staticmethod
     def _linearize(pde, m_at, t):
-        raise NotImplementedError("SemiLinearWhiteNoiseEK1 is scheduled after the linear path (DESIGN.md, row f2)")
+        fx = np.asarray(pde.f(t, m_at), dtype=np.float64)
+        Jx = np.asarray(pde.df(t, m_at), dtype=np.float64)
+        return pde.L + Jx, Jx @ m_at - fx
 
-    def attempt_step(self, state, dt, pde):
-        raise NotImplementedError("SemiLinearWhiteNoiseEK1 is scheduled after the linear path (DESIGN.md, row f2)")
+    def solve_marginals(self, pde, *, num_steps=None):
+        raise TypeError("solve_marginals keeps the loop on the device and needs a linear PDE; use solve()")

@@ -145,3 +145,21 @@ def test_no_cpu_fallback_and_no_oracle_import_in_product():
         s = pnmol.white.LinearWhiteNoiseEK1(steprule=pnmol.odetools.step.Constant(0.1))
         with pytest.raises(_hip.PnmolHipError):
             s.initialize(p)
+
+
+@pytest.mark.parametrize("bcond", ["dirichlet", "neumann"])
+def test_spruce_budworm_recipe_matches_oracle(bcond):  # reference pde/examples.py:251-341
+    kw = dict(tmax=1.0, dx=0.1, diffusion_rate=0.05, bcond=bcond)
+    p = pnmol.pde.examples.spruce_budworm_1d_discretized(kernel=kernels.SquareExponential(), **kw)
+    q = o.spruce_budworm_1d_discretized(kernel=o.SquareExponential(), **kw)
+    for name in ("L", "B", "R_sqrtm", "y0"):
+        np.testing.assert_allclose(getattr(p, name), getattr(q, name), rtol=1e-13, atol=1e-15)
+    x = np.linspace(0.05, 0.4, 11)
+    np.testing.assert_allclose(p.f(0.3, x), q.f(0.3, x))
+    np.testing.assert_allclose(p.df(0.3, x), q.df(0.3, x))
+    h = 1e-6   # df is the Jacobian of f
+    J = np.stack([(p.f(0, x + h * e) - p.f(0, x - h * e)) / (2 * h) for e in np.eye(11)], axis=1)
+    np.testing.assert_allclose(p.df(0, x), J, atol=1e-8)
+    M, shift = pnmol.white.SemiLinearWhiteNoiseEK1._linearize(p, x, 0.0)
+    np.testing.assert_allclose(M, p.L + p.df(0, x))
+    np.testing.assert_allclose(shift, p.df(0, x) @ x - p.f(0, x))
