@@ -72,12 +72,23 @@ def cpu_baseline(seconds_budget=20.0):
                       f"(LAPACK, threaded BLAS on all host cores), square-root form as written"}
 
 
+def _hip_device_count():
+    import ctypes
+    from pnmol import _hip
+    n = ctypes.c_int(0)
+    _hip.load_library().pnmol_device_count(ctypes.byref(n))
+    return n.value
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--problems-per-gpu", type=int, default=1,
+                    help="independent problems run concurrently on each GPU (one context/stream and host thread each); "
+                         "the headline metric uses 1")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -99,30 +110,49 @@ def main():
     os.environ["PNMOL_HIP_DEVICE"] = str(local_rank)
 
     from pnmol import _hip, batch
-    # one problem per rank: problem g of the 8-problem diffusion sweep (kappa = 0.05 for the single-GPU headline)
-    kappa = 0.05 if world == 1 else batch.diffusion_sweep(batch.shard(world, rank, world)[0], max(world, 8))
-    pde, solver = build_problem(kappa, args.steps + args.warmup)
-    state = solver.initialize(pde)
-    flt, dev = solver._device_filter, state.y.device_state
-    solver._ensure_error_model(pde, DT)
-    ctx = _hip.Context.default()
+    B = max(1, args.problems_per_gpu)
+    # one problem per rank: problem g of the 8-problem diffusion sweep (kappa = 0.05 for the single-GPU headline);
+    # with --problems-per-gpu B every rank owns B consecutive problems of a (world*B)-problem sweep
+    probs = []
+    for b in range(B):
+        gidx = rank * B + b
+        kappa = 0.05 if world * B == 1 else batch.diffusion_sweep(gidx, max(world * B, 8))
+        pde, solver = build_problem(kappa, args.steps + args.warmup)
+        ctx = _hip.Context(local_rank % max(1, _hip_device_count()))   # own stream per problem
+        solver._context = ctx
+        state = solver.initialize(pde)
+        flt, dev = solver._device_filter, state.y.device_state
+        solver._ensure_error_model(pde, DT)
+        probs.append((ctx, flt, dev))
 
     def sync_all():
-        ctx.synchronize()
+        for ctx, _, _ in probs:
+            ctx.synchronize()
         if dist is not None:
             import torch
             dist.barrier()
             torch.cuda.synchronize()
 
+    def run_all(k, outputs):
+        # enqueue every problem's k steps (asynchronous), then collect: the streams run concurrently on the device
+        for _, flt, dev in probs:
+            flt.steps_begin(dev, k, DT)
+        return [flt.steps_end(dev, want_means=outputs, want_stds=outputs) for _, flt, dev in probs]
+
     if args.warmup > 0:
-        flt.steps(dev, args.warmup, DT, want_means=False, want_stds=False)
-    flt.prepare_steps(dev, args.steps, DT)   # one-off host work (buffers, hipGraph instantiation)
+        run_all(args.warmup, False)
+    for _, flt, dev in probs:
+        flt.prepare_steps(dev, args.steps, DT)   # one-off host work (buffers, hipGraph instantiation)
     sync_all()
     t0 = time.perf_counter()
-    means, stds, infos = flt.steps(dev, args.steps, DT)     # K steps, one host sync at the end
+    results = run_all(args.steps, True)                       # K steps per problem, one host sync at the end
     sync_all()
     wall = time.perf_counter() - t0
-    dev_ms = flt.last_steps_ms()                              # HIP events on the ctx stream
+    dev_ms = max(p[1].last_steps_ms() for p in probs)         # HIP events on each problem's stream
+    means, stds, infos = results[0]
+    for mm_, ss_, ii_ in results[1:]:
+        means, stds = np.concatenate([means, mm_]), np.concatenate([stds, ss_])
+        infos = list(infos) + list(ii_)
 
     sig = np.array([o.diffusion_squared_local for o in infos])
     ok = bool(np.all(np.isfinite(means)) and np.all(np.isfinite(stds)) and all(o.info == -1 for o in infos))
@@ -135,9 +165,11 @@ def main():
     if rank == 0:
         n, d = NU + 1, MESH_N
         D, m = n * d, d + 2
-        steps_per_s = world * args.steps / wall
+        steps_per_s = world * B * args.steps / wall
         flops = f_alg(D, m, n)
-        step_ms_dev = dev_ms / args.steps
+        # B = 1: HIP events on the launch stream.  B > 1: the streams overlap only partially, so the honest
+        # per-step device time is the wall time of the whole batch divided by all its steps.
+        step_ms_dev = dev_ms / args.steps if B == 1 else 1e3 * wall / (args.steps * B)
         achieved = flops / (step_ms_dev * 1e-3) / 1e12
         traffic = None
         try:   # HBM bytes per step from the committed PMC profile (rocprofv3 cannot run inside this process)
@@ -151,7 +183,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"1-D heat equation, N={MESH_N} mesh, IWP(nu={NU}) EK1, Dirichlet, dt=2^-7, "
                                    f"one problem per GPU (kappa sweep), D={D}, m={m}",
-                       "steps_in_one_call": args.steps, "valid": ok,
+                       "steps_in_one_call": args.steps, "valid": ok, "problems_per_gpu": B,
                        "device_ms_per_step": step_ms_dev},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,

@@ -109,6 +109,13 @@ int pnmol_filter_step(pnmol_filter* f, const pnmol_state* in, double dt, pnmol_s
 int pnmol_filter_steps(pnmol_filter* f, pnmol_state* s, int k, double dt, double* means_kd,
                        double* stds_kd, pnmol_step_out* info_k);
 
+/* The same loop split in two, so that one host thread can keep several contexts (several problems on one GPU, or
+ * several GPUs) busy: `_begin` enqueues the k steps and the read-out copies and returns without waiting, `_end`
+ * waits for that context's stream and fills the caller's buffers.  One `_begin` may be outstanding per filter. */
+int pnmol_filter_steps_begin(pnmol_filter* f, pnmol_state* s, int k, double dt);
+int pnmol_filter_steps_end(pnmol_filter* f, pnmol_state* s, double* means_kd, double* stds_kd,
+                           pnmol_step_out* info_k);
+
 /* Optional: do the one-off host work of a following `pnmol_filter_steps(f, s, k, dt, ...)` now
  * (output buffers, capture + instantiation of the hipGraphs the step loop is replayed from). */
 int pnmol_filter_prepare_steps(pnmol_filter* f, pnmol_state* s, int k, double dt);

@@ -957,6 +957,9 @@ struct pnmol_filter {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.f;
     int* ctr = nullptr;  // device step counter (slot of the per-step outputs)
+    int pending_k = 0;   // steps enqueued by pnmol_filter_steps_begin and not yet collected
+    double pending_dt = 0.0;
+    pnmol_state* pending_state = nullptr;
     struct GraphEntry {
         double *P0, *P1, *var;
         double dt;
@@ -1597,10 +1600,9 @@ int pnmol_filter_step(pnmol_filter* f, const pnmol_state* in, double dt, pnmol_s
     return 0;
 }
 
-int pnmol_filter_steps(pnmol_filter* f, pnmol_state* s, int k, double dt, double* means_kd, double* stds_kd,
-                       pnmol_step_out* info_k) {
+int pnmol_filter_steps_begin(pnmol_filter* f, pnmol_state* s, int k, double dt) {
     if (!f || !s || s->f != f || k < 1 || !(dt > 0.0)) {
-        if (f) f->ctx->err = "pnmol_filter_steps: bad argument";
+        if (f) f->ctx->err = "pnmol_filter_steps_begin: bad argument";
         return -1;
     }
     pnmol_ctx* ctx = f->ctx;
@@ -1650,20 +1652,41 @@ int pnmol_filter_steps(pnmol_filter* f, pnmol_state* s, int k, double dt, double
         f->tmpP = s->P, f->tmpMean = s->mean;
         s->P = curP, s->mean = curM;
     }
-    // device -> pinned staging (allocated in ensure_rec) -> caller's buffers
-    double* rec = f->h_pin;
-    double* hm = rec + (size_t)4 * f->rec_cap;
-    double* hs = hm + (size_t)f->rec_cap * f->d;
-    int* inf = reinterpret_cast<int*>(hs + (size_t)f->rec_cap * f->d);
-    HIPCHK(ctx, hipMemcpyAsync(rec, f->rec, sizeof(double) * 4 * k, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipMemcpyAsync(inf, f->info, sizeof(int) * k, hipMemcpyDeviceToHost, st));
-    if (means_kd) HIPCHK(ctx, hipMemcpyAsync(hm, f->rec_means, sizeof(double) * (size_t)k * f->d, hipMemcpyDeviceToHost, st));
-    if (stds_kd) HIPCHK(ctx, hipMemcpyAsync(hs, f->rec_stds, sizeof(double) * (size_t)k * f->d, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipStreamSynchronize(st));
-    HIPCHK(ctx, hipEventElapsedTime(&f->last_ms, f->ev0, f->ev1));
+    // device -> pinned staging (allocated in ensure_rec); handed to the caller by pnmol_filter_steps_end
+    HIPCHK(ctx, hipMemcpyAsync(f->h_pin, f->rec, sizeof(double) * 4 * k, hipMemcpyDeviceToHost, st));
+    {
+        double* hm = f->h_pin + (size_t)4 * f->rec_cap;
+        double* hs = hm + (size_t)f->rec_cap * f->d;
+        int* inf = reinterpret_cast<int*>(hs + (size_t)f->rec_cap * f->d);
+        HIPCHK(ctx, hipMemcpyAsync(inf, f->info, sizeof(int) * k, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(hm, f->rec_means, sizeof(double) * (size_t)k * f->d, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(hs, f->rec_stds, sizeof(double) * (size_t)k * f->d, hipMemcpyDeviceToHost, st));
+    }
     if (trace)
-        std::fprintf(stderr, "[pnmol] steps(k=%d): prepare %.2f ms, enqueue %.2f ms, wait+copy %.2f ms, device %.2f ms, graphs big=%d pair=%d\n",
-                     k, tB - tA, tC - tB, now() - tC, f->last_ms, gbig != nullptr, gpair != nullptr);
+        std::fprintf(stderr, "[pnmol] steps_begin(k=%d): prepare %.2f ms, enqueue %.2f ms, graphs big=%d pair=%d\n", k, tB - tA,
+                     tC - tB, gbig != nullptr, gpair != nullptr);
+    f->pending_k = k;
+    f->pending_dt = dt;
+    f->pending_state = s;
+    return 0;
+}
+
+int pnmol_filter_steps_end(pnmol_filter* f, pnmol_state* s, double* means_kd, double* stds_kd, pnmol_step_out* info_k) {
+    if (!f || !s || f->pending_state != s || f->pending_k < 1) {
+        if (f) f->ctx->err = "pnmol_filter_steps_end: no matching pnmol_filter_steps_begin";
+        return -1;
+    }
+    pnmol_ctx* ctx = f->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int k = f->pending_k;
+    const double dt = f->pending_dt;
+    f->pending_k = 0, f->pending_state = nullptr;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipEventElapsedTime(&f->last_ms, f->ev0, f->ev1));
+    const double* rec = f->h_pin;
+    const double* hm = rec + (size_t)4 * f->rec_cap;
+    const double* hs = hm + (size_t)f->rec_cap * f->d;
+    const int* inf = reinterpret_cast<const int*>(hs + (size_t)f->rec_cap * f->d);
     if (means_kd) std::memcpy(means_kd, hm, sizeof(double) * (size_t)k * f->d);
     if (stds_kd) std::memcpy(stds_kd, hs, sizeof(double) * (size_t)k * f->d);
     const bool have_sq = (f->Sqinv != nullptr && f->sq_dt == dt);
@@ -1683,6 +1706,13 @@ int pnmol_filter_steps(pnmol_filter* f, pnmol_state* s, int k, double dt, double
         return -3;
     }
     return 0;
+}
+
+int pnmol_filter_steps(pnmol_filter* f, pnmol_state* s, int k, double dt, double* means_kd, double* stds_kd,
+                       pnmol_step_out* info_k) {
+    const int rc = pnmol_filter_steps_begin(f, s, k, dt);
+    if (rc != 0) return rc;
+    return pnmol_filter_steps_end(f, s, means_kd, stds_kd, info_k);
 }
 
 int pnmol_filter_prepare_steps(pnmol_filter* f, pnmol_state* s, int k, double dt) {

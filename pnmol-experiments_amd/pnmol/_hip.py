@@ -66,6 +66,8 @@ SYMBOLS = {
     "pnmol_filter_step": (ctypes.c_int, [_vp, _vp, ctypes.c_double, _vp, ctypes.POINTER(StepOut), _c_double_p]),
     "pnmol_filter_steps": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_double, _c_double_p, _c_double_p,
                                           ctypes.POINTER(StepOut)]),
+    "pnmol_filter_steps_begin": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_double]),
+    "pnmol_filter_steps_end": (ctypes.c_int, [_vp, _vp, _c_double_p, _c_double_p, ctypes.POINTER(StepOut)]),
     "pnmol_filter_prepare_steps": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_double]),
     "pnmol_filter_last_steps_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "pnmol_filter_debug_read": (ctypes.c_int, [_vp, ctypes.c_int, _c_double_p, ctypes.c_long]),
@@ -205,6 +207,21 @@ class Filter:
         rc = self.lib.pnmol_filter_steps(self.handle, state.handle, int(k), float(dt),
                                          _dp(means) if want_means else None, _dp(stds) if want_stds else None, infos)
         self.ctx.check(rc, "pnmol_filter_steps")
+        return means, stds, infos
+
+    def steps_begin(self, state, k, dt):
+        self.ctx.check(self.lib.pnmol_filter_steps_begin(self.handle, state.handle, int(k), float(dt)),
+                       "pnmol_filter_steps_begin")
+        self._pending_k = int(k)
+
+    def steps_end(self, state, want_means=True, want_stds=True):
+        k = self._pending_k
+        means = np.empty((k, self.d)) if want_means else None
+        stds = np.empty((k, self.d)) if want_stds else None
+        infos = (StepOut * k)()
+        rc = self.lib.pnmol_filter_steps_end(self.handle, state.handle, _dp(means) if want_means else None,
+                                             _dp(stds) if want_stds else None, infos)
+        self.ctx.check(rc, "pnmol_filter_steps_end")
         return means, stds, infos
 
     def prepare_steps(self, state, k, dt):

@@ -37,8 +37,10 @@ class _WhiteNoiseEK1Base(pdefilter.PDEFilter):
                                                wp_diffusion_sqrtm=diffusion_state_sqrtm)
         return prior, prior.projection_matrix(0), prior.projection_matrix(1), diffusion_state_sqrtm
 
+    _context = None   # set to an `_hip.Context` to run this solver on its own device / stream
+
     def _bind(self, pde, gamma):
-        ctx = _hip.Context.default()
+        ctx = self._context or _hip.Context.default()
         self._device_filter = _hip.Filter(ctx, L=pde.L, B=pde.B, E_sqrtm=pde.E_sqrtm, R_sqrtm=pde.R_sqrtm, Gamma=gamma,
                                           num_derivatives=self.num_derivatives)
         self._device_pde = pde
