@@ -47,11 +47,17 @@ typedef struct pnmol_filter_desc {
     int d;                 /* mesh points = pde.L.shape[0]                            */
     int num_derivatives;   /* nu; n = nu + 1 in {2,3,4}                               */
     int nB;                /* rows of pde.B                                           */
-    const double* L;       /* (d,d)  pde.L                                            */
-    const double* B;       /* (nB,d) pde.B                                            */
+    const double* L;       /* (d,d_state)  pde.L                                      */
+    const double* B;       /* (nB,d_state) pde.B                                      */
     const double* E_sqrtm; /* (d,d)  pde.E_sqrtm                                      */
     const double* R_sqrtm; /* (nB,nB) pde.R_sqrtm                                     */
     const double* Gamma;   /* (d,d) lower; iwp.wp_diffusion_sqrtm (base/iwp.py:10)    */
+    int d_state;           /* 0 or d: white-noise model.  2d: latent-force model (latent.py:11-292), whose state is
+                              [u; eps] = two stacked IWPs (base/stacked_ssm.py): then L is (d, 2d) = [L, I]
+                              (H_ode = E1 - L E0 - E0_eps, latent.py:253-257), B is (nB, 2d) = [B, 0], Gamma is
+                              (2d, 2d) = blockdiag(chol K, E_sqrtm) (latent.py:136-153), E_sqrtm/R_sqrtm are the
+                              measurement noise factors (zero: update_sqrt_no_meascov, latent.py:197).  State
+                              buffers are then (n, 2d) / (2D, 2D) in the reference's glued order (latent.py:163-175). */
 } pnmol_filter_desc;
 
 int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_filter** out);
@@ -67,11 +73,11 @@ int pnmol_filter_set_error_model(pnmol_filter* f, double dt, const double* Sq_in
 /* Semilinear EK1 (`SemiLinearWhiteNoiseEK1.evaluate_ode`, white.py:189-208): the measurement rows become
  * H_ode = E1 - (J_x + L) E0 with shift b = J_x m_at - f(t, m_at), re-linearised at every step.
  * `pnmol_filter_predict_mean` returns m_at = E0 P m^- (predicted derivative-0 mean, raw coordinates) for a step
- * of size dt from `in`; the caller evaluates f and df there and passes M = J_x + L (d,d) and shift (d) to
+ * of size dt from `in`; the caller evaluates f and df there and passes M = J_x + L (d,d_state) and shift (d) to
  * `pnmol_filter_set_operator` (NULL shift = zeros), which replaces the stencil rows used by the following
  * `pnmol_filter_step(s)` calls.  The boundary rows B are kept. */
 int pnmol_filter_predict_mean(pnmol_filter* f, const pnmol_state* in, double dt, double* m_at_d);
-int pnmol_filter_set_operator(pnmol_filter* f, const double* M_dd, const double* shift_d);
+int pnmol_filter_set_operator(pnmol_filter* f, const double* M_dds, const double* shift_d);
 
 /* states ----------------------------------------------------------------------------- */
 int pnmol_state_create(pnmol_filter* f, pnmol_state** out);

@@ -367,12 +367,13 @@ def heat_1d_discretized(*, bbox=None, dx=0.05, stencil_size_interior=3, stencil_
 
 
 def spruce_budworm_1d_discretized(*, bbox=None, t0=0.0, tmax=10.0, diffusion_rate=1.0, dx=0.1, kernel=None,
-                                  stencil_size_interior=3, stencil_size_boundary=3, bcond="dirichlet", growth_rate=1.0):
+                                  stencil_size_interior=3, stencil_size_boundary=3, bcond="dirichlet", growth_rate=1.0,
+                                  nugget_gram_matrix_fd=0.0):
     """examples.py:251-341: Fisher's equation u_t = kappa u_xx + c u (1 - u); y0 = 0.1 sin(pi x)."""
     p = heat_1d_discretized(bbox=bbox, dx=dx, stencil_size_interior=stencil_size_interior,
                             stencil_size_boundary=stencil_size_boundary, t0=t0, tmax=tmax,
                             y0_fun=lambda x: 0.1 * np.sin(np.pi * x), diffusion_rate=diffusion_rate, kernel=kernel,
-                            bcond=bcond)
+                            bcond=bcond, nugget_gram_matrix_fd=nugget_gram_matrix_fd)
     p.f = lambda _t, x: growth_rate * x * (1.0 - x)
     p.df = lambda _t, x: np.diag(growth_rate * (1.0 - 2.0 * x))
     return p
@@ -691,6 +692,119 @@ class WhiteNoiseEK1:
                 d2.append(state.diffusion_squared_local)
         c = state.y.cov_sqrtm * np.sqrt(np.mean(np.array(d2)))
         return state._replace(y=state.y._replace(cov_sqrtm=c)), info
+
+
+# --------------------------------------------------------------------------------------
+# Latent-force EK1 (reference: latent.py:11-292, base/stacked_ssm.py:7-80).  The state is the
+# stack [u; eps] of two IWPs (diffusions chol K and pde.E_sqrtm); the PDE rows measure
+# E1 u - L E0 u - E0 eps, the BC rows B E0 u, both noise-free (update_sqrt_no_meascov).
+# Parity: pinned only by the reference's no-NaN smoke test (tests/test_pdefilter.py:140-145),
+# i.e. numerically UNPINNED; the covariance-form restatement below is the cross-check.
+# --------------------------------------------------------------------------------------
+
+
+class LatentForceEK1(WhiteNoiseEK1):
+    """`LinearLatentForceEK1` (semilinear=False) / `SemiLinearLatentForceEK1` (True)."""
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self.state_iwp = self.lf_iwp = None
+
+    # ---- latent.py:241-292
+    def evaluate_ode(self, pde, p0, p1, m_pred, t, p_state, p_eps):
+        L, B = pde.L, pde.B
+        E0s, E0e, E1s = p0 @ p_state, p0 @ p_eps, p1 @ p_state
+        m_at = scipy.linalg.block_diag(E0s, E0e) @ m_pred
+        state_at = m_at[: m_at.shape[0] // 2]
+        if self.semilinear:
+            fx, Jx = pde.f(t, state_at), pde.df(t, state_at)
+            H_state = E1s - Jx @ E0s - L @ E0s
+        else:
+            fx, Jx = L @ state_at, L
+            H_state = E1s - Jx @ E0s
+        Hb = B @ E0s
+        H = np.block([[H_state, -E0e], [Hb, np.zeros_like(Hb)]])
+        z = H @ m_pred + np.hstack((Jx @ state_at - fx, np.zeros(B.shape[0])))
+        return z, H
+
+    # ---- latent.py:136-153
+    def initialize_iwp_latent(self, pde):
+        X = pde.mesh_spatial.points
+        gamma = np.linalg.cholesky(self.spatial_kernel(X, X.T))
+        d = pde.y0.shape[0]
+        prior_state, prior_latent = IWP(d, self.num_derivatives, gamma), IWP(d, self.num_derivatives, pde.E_sqrtm)
+        return prior_state, prior_latent, prior_latent.projection_matrix(0), prior_latent.projection_matrix(1), gamma
+
+    # ---- latent.py:20-134
+    def initialize(self, pde):
+        self.state_iwp, self.lf_iwp, self.E0, self.E1, gamma = self.initialize_iwp_latent(pde)
+        self.iwp = self.state_iwp
+        n, d = self.num_derivatives + 1, pde.L.shape[0]
+        c0 = self.diffuse_prior_scale * np.eye(n)
+        C_state, C_latent = np.kron(gamma, c0), np.kron(pde.E_sqrtm, c0)
+        C_y0, k_y0, _ = update_sqrt(self.E0, C_state, 1e-6 * np.eye(d))
+        m_stack = np.hstack((k_y0 @ pde.y0, np.zeros(n * d)))
+        C_block = scipy.linalg.block_diag(C_y0, C_latent)
+        eye = np.eye(n * d)
+        z, H = self.evaluate_ode(pde, self.E0, self.E1, m_stack, pde.t0, eye, eye)
+        C0, k, _ = update_sqrt(H, C_block, 1e-6 * np.eye(d + pde.B.shape[0]))
+        m0 = m_stack - k @ z
+        glued = np.hstack((m0[: n * d].reshape((n, d), order="F"), m0[n * d:].reshape((n, d), order="F")))
+        return FilterState(t=pde.t0, y=MVN(glued, C0), error_estimate=None, reference_state=None,
+                           diffusion_squared_local=[])
+
+    # ---- latent.py:155-233 (stacked_ssm.py:17-52: block_diag of the two processes)
+    def attempt_step(self, state, dt, pde):
+        Ps, Pis = self.state_iwp.nordsieck_preconditioner(dt)
+        Pe, Pie = self.lf_iwp.nordsieck_preconditioner(dt)
+        P, Pinv = scipy.linalg.block_diag(Ps, Pe), scipy.linalg.block_diag(Pis, Pie)
+        (As, Qs), (Ae, Qe) = self.state_iwp.preconditioned_discretize, self.lf_iwp.preconditioned_discretize
+        A, Ql = scipy.linalg.block_diag(As, Ae), scipy.linalg.block_diag(Qs, Qe)
+        n, d = self.num_derivatives + 1, pde.y0.shape[0]
+        flat = np.hstack((state.y.mean[:, :d].reshape((-1,), order="F"), state.y.mean[:, d:].reshape((-1,), order="F")))
+        m, Cl = Pinv @ flat, Pinv @ state.y.cov_sqrtm
+        mp = A @ m
+        z, H = self.evaluate_ode(pde, self.E0, self.E1, mp, state.t + dt, Ps, Pe)
+        Clp = propagate_cholesky_factor(A @ Cl, Ql)
+        Cl_new, K, Sl = update_sqrt(H, Clp, None)
+        m_new = P @ (mp - K @ z)
+        Cl_new = P @ Cl_new
+        if self.canonical_factor_signs:  # quirk Q1, as in WhiteNoiseEK1.attempt_step
+            Sl = Sl * np.sign(np.diag(Sl))[None, :]
+        r = scipy.linalg.solve_triangular(Sl.T, z, lower=False)
+        glued = np.hstack((m_new[: n * d].reshape((n, d), order="F"), m_new[n * d:].reshape((n, d), order="F")))
+        new = FilterState(t=state.t + dt, y=MVN(glued, Cl_new), error_estimate=None, reference_state=None,
+                          diffusion_squared_local=r @ r / r.shape[0])
+        return new, dict(num_f_evaluations=1, num_df_evaluations=1)
+
+
+def read_mean_and_std_latent(sol, E0):
+    """experiments/figure1.py:83-89: the state half of the glued mean and marginal std."""
+    d = sol.mean.shape[-1] // 2
+    var = np.einsum("tij,tij->ti", sol.cov_sqrtm, sol.cov_sqrtm)
+    return sol.mean[:, 0, :d], np.sqrt(var[:, : var.shape[1] // 2] @ E0.T)
+
+
+def latent_covariance_form_step(solver, pde, glued_mean, cov, dt, t):
+    """`LatentForceEK1.attempt_step` in covariance form (cov is (2D,2D) in the reference's stacked order).
+    Returns (glued mean (n,2d), cov, z^T S^-1 z / m).  S may be semi-definite (exact Dirichlet rows): pinv."""
+    n, d = solver.num_derivatives + 1, pde.y0.shape[0]
+    Ps, Pis = solver.state_iwp.nordsieck_preconditioner(dt)
+    Pe, Pie = solver.lf_iwp.nordsieck_preconditioner(dt)
+    P, Pinv = scipy.linalg.block_diag(Ps, Pe), scipy.linalg.block_diag(Pis, Pie)
+    (As, Qs), (Ae, Qe) = solver.state_iwp.preconditioned_discretize, solver.lf_iwp.preconditioned_discretize
+    A, Ql = scipy.linalg.block_diag(As, Ae), scipy.linalg.block_diag(Qs, Qe)
+    flat = np.hstack((glued_mean[:, :d].reshape((-1,), order="F"), glued_mean[:, d:].reshape((-1,), order="F")))
+    mp = A @ (Pinv @ flat)
+    Pm = A @ (Pinv @ cov @ Pinv.T) @ A.T + Ql @ Ql.T
+    z, H = solver.evaluate_ode(pde, solver.E0, solver.E1, mp, t + dt, Ps, Pe)
+    S = H @ Pm @ H.T
+    Si = np.linalg.pinv(S, rcond=1e-13, hermitian=True)
+    K = Pm @ H.T @ Si
+    m_new = P @ (mp - K @ z)
+    C_new = P @ (Pm - K @ S @ K.T) @ P.T
+    glued = np.hstack((m_new[: n * d].reshape((n, d), order="F"), m_new[n * d:].reshape((n, d), order="F")))
+    return glued, C_new, z @ Si @ z / z.shape[0]
 
 
 def read_mean_and_std(sol, E0):

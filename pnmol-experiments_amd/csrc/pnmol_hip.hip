@@ -937,6 +937,7 @@ struct pnmol_ctx {
 struct pnmol_filter {
     pnmol_ctx* ctx = nullptr;
     int d = 0, n = 0, nu = 0, nB = 0, m = 0, dp = 0, mp = 0, CB = 0, RBS = 0, RBW = 0, RT = 0, ellw = 0;
+    int ds = 0;  // spatial components of the state (= d, or 2d for the latent-force model [u; eps])
     long Dp = 0;
     IwpConsts iwp{};
     int* ell_col = nullptr;
@@ -1088,21 +1089,22 @@ int get_graph(pnmol_filter* f, double* P0, double* M0, double* P1, double* M1, d
 }
 
 // ELL image of Hv = [-M; B] (rows padded to mp, arrays [e*mp + i]); returns the width
-int build_ell(const double* M, const double* B, int d, int nB, int mp, std::vector<int>& ecol, std::vector<double>& eval) {
+int build_ell(const double* M, const double* B, int d, int ds, int nB, int mp, std::vector<int>& ecol,
+              std::vector<double>& eval) {
     const int m = d + nB;
     int w = 1;
     for (int i = 0; i < m; ++i) {
         int c = 0;
-        const double* row = i < d ? M + (long)i * d : B + (long)(i - d) * d;
-        for (int k = 0; k < d; ++k) c += row[k] != 0.0;
+        const double* row = i < d ? M + (long)i * ds : B + (long)(i - d) * ds;
+        for (int k = 0; k < ds; ++k) c += row[k] != 0.0;
         w = c > w ? c : w;
     }
     ecol.assign((size_t)w * mp, -1);
     eval.assign((size_t)w * mp, 0.0);
     for (int i = 0; i < m; ++i) {
         int e = 0;
-        for (int k = 0; k < d; ++k) {
-            const double v = i < d ? -M[(long)i * d + k] : B[(long)(i - d) * d + k];
+        for (int k = 0; k < ds; ++k) {
+            const double v = i < d ? -M[(long)i * ds + k] : B[(long)(i - d) * ds + k];
             if (v != 0.0) {
                 ecol[(size_t)e * mp + i] = k;  // state index (0, k) = k
                 eval[(size_t)e * mp + i] = v;
@@ -1209,7 +1211,8 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
     if (!ctx || !desc || !out) return -1;
     *out = nullptr;
     const int d = desc->d, nu = desc->num_derivatives, nB = desc->nB, n = nu + 1;
-    if (d < 1 || nu < 1 || n > MAXN || nB < 0 || !desc->L || !desc->E_sqrtm || !desc->Gamma ||
+    const int ds = desc->d_state > 0 ? desc->d_state : d;
+    if (d < 1 || ds < d || nu < 1 || n > MAXN || nB < 0 || !desc->L || !desc->E_sqrtm || !desc->Gamma ||
         (nB > 0 && (!desc->B || !desc->R_sqrtm))) {
         ctx->err = "pnmol_filter_create: bad descriptor (need d>=1, 1<=nu<=3, non-null L/B/E_sqrtm/R_sqrtm/Gamma)";
         return -1;
@@ -1217,8 +1220,8 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
     HIPCHK(ctx, hipSetDevice(ctx->device));
     pnmol_filter* f = new pnmol_filter();
     f->ctx = ctx;
-    f->d = d, f->nu = nu, f->n = n, f->nB = nB, f->m = d + nB;
-    f->dp = round_up(d, NB), f->mp = round_up(f->m, NB);
+    f->d = d, f->ds = ds, f->nu = nu, f->n = n, f->nB = nB, f->m = d + nB;
+    f->dp = round_up(ds, NB), f->mp = round_up(f->m, NB);
     f->Dp = (long)n * f->dp;
     f->CB = f->mp / NB, f->RBS = f->mp / NB, f->RBW = (int)(f->Dp / NB), f->RT = f->RBS + f->RBW + 1 + f->RBS;  // [S; W; z-block; I]
     const int dp = f->dp, mp = f->mp, m = f->m;
@@ -1240,8 +1243,8 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
     // Hv = [-L; B] in ELL, rows padded to mp
     std::vector<int> ecol;
     std::vector<double> eval;
-    f->hB.assign(desc->B ? desc->B : nullptr, desc->B ? desc->B + (size_t)nB * d : nullptr);
-    const int w = build_ell(desc->L, f->hB.data(), d, nB, mp, ecol, eval);
+    f->hB.assign(desc->B ? desc->B : nullptr, desc->B ? desc->B + (size_t)nB * ds : nullptr);
+    const int w = build_ell(desc->L, f->hB.data(), d, ds, nB, mp, ecol, eval);
     f->ellw = w;
     f->ell_cap = w;
     // R = blockdiag(E E^T, Rb Rb^T): diagonal fast path, dense otherwise
@@ -1279,10 +1282,10 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
     }
     // K = Gamma Gamma^T (white.py:84-85, base/iwp.py:49-52), padded
     std::vector<double> Kg((size_t)dp * dp, 0.0);
-    for (int i = 0; i < d; ++i)
+    for (int i = 0; i < ds; ++i)
         for (int k = 0; k <= i; ++k) {
             double s = 0.0;
-            for (int q = 0; q <= k; ++q) s += desc->Gamma[(long)i * d + q] * desc->Gamma[(long)k * d + q];
+            for (int q = 0; q <= k; ++q) s += desc->Gamma[(long)i * ds + q] * desc->Gamma[(long)k * ds + q];
             Kg[(size_t)i * dp + k] = Kg[(size_t)k * dp + i] = s;
         }
 
@@ -1388,7 +1391,7 @@ int pnmol_filter_set_operator(pnmol_filter* f, const double* M_dd, const double*
     HIPCHK(ctx, hipSetDevice(ctx->device));
     std::vector<int> ecol;
     std::vector<double> eval;
-    const int w = build_ell(M_dd, f->hB.data(), f->d, f->nB, f->mp, ecol, eval);
+    const int w = build_ell(M_dd, f->hB.data(), f->d, f->ds, f->nB, f->mp, ecol, eval);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     drop_graphs(f);  // the stencil width / pointers are baked into captured launches
     if (w > f->ell_cap) {
@@ -1479,7 +1482,7 @@ int pnmol_state_set(pnmol_state* s, double t, const double* mean_nd, const doubl
     pnmol_filter* f = s->f;
     pnmol_ctx* ctx = f->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    const int n = f->n, d = f->d, dp = f->dp;
+    const int n = f->n, d = f->ds, dp = f->dp;
     const long D = (long)n * d, Dp = f->Dp;
     std::vector<double> hm((size_t)Dp, 0.0), hv((size_t)Dp, 0.0), hP((size_t)Dp * Dp, 0.0);
     for (int a = 0; a < n; ++a)
@@ -1524,7 +1527,7 @@ int pnmol_state_get_mean(const pnmol_state* s, double* mean_nd) {
     double sc[MAXN];
     frame_scales(s, sc);
     for (int a = 0; a < f->n; ++a)
-        for (int j = 0; j < f->d; ++j) mean_nd[(size_t)a * f->d + j] = sc[a] * hm[(size_t)a * f->dp + j];
+        for (int j = 0; j < f->ds; ++j) mean_nd[(size_t)a * f->ds + j] = sc[a] * hm[(size_t)a * f->dp + j];
     return 0;
 }
 
@@ -1539,7 +1542,7 @@ int pnmol_state_get_marginal_var(const pnmol_state* s, double* var_nd) {
     double sc[MAXN];
     frame_scales(s, sc);
     for (int a = 0; a < f->n; ++a)
-        for (int j = 0; j < f->d; ++j) var_nd[(size_t)a * f->d + j] = sc[a] * sc[a] * hv[(size_t)a * f->dp + j];
+        for (int j = 0; j < f->ds; ++j) var_nd[(size_t)a * f->ds + j] = sc[a] * sc[a] * hv[(size_t)a * f->dp + j];
     return 0;
 }
 
@@ -1548,7 +1551,7 @@ int pnmol_state_get_cov(const pnmol_state* s, double* cov_DD) {
     pnmol_filter* f = s->f;
     pnmol_ctx* ctx = f->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    const int n = f->n, d = f->d, dp = f->dp;
+    const int n = f->n, d = f->ds, dp = f->dp;
     const long D = (long)n * d, Dp = f->Dp;
     std::vector<double> hP((size_t)Dp * Dp);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

@@ -1,7 +1,7 @@
 """PNMOL on MI355X: host-side mirror of the reference's `pnmol` package for the white-noise
-EK1 path (reference: src/pnmol/__init__.py).  Cold path (mesh, kernels, discretisation,
+and latent-force EK1 paths (reference: src/pnmol/__init__.py).  Cold path (mesh, kernels, discretisation,
 problem recipes) is NumPy on the host; the filter step runs in libpnmol_hip.so."""
 
-from . import diffops, discretize, kernels, mesh, odetools, pde, pdefilter, white  # noqa: F401
+from . import diffops, discretize, kernels, latent, mesh, odetools, pde, pdefilter, white  # noqa: F401
 
 __version__ = "0.1.0"

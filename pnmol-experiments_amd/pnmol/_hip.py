@@ -38,6 +38,7 @@ class FilterDesc(ctypes.Structure):
         ("E_sqrtm", _c_double_p),
         ("R_sqrtm", _c_double_p),
         ("Gamma", _c_double_p),
+        ("d_state", ctypes.c_int),
     ]
 
 
@@ -148,11 +149,12 @@ class Filter:
 
     def __init__(self, ctx, *, L, B, E_sqrtm, R_sqrtm, Gamma, num_derivatives):
         self.ctx, self.lib = ctx, ctx.lib
-        d = L.shape[0]
+        d, ds = L.shape          # ds = d (white-noise model) or 2d (latent-force model, state [u; eps])
         nB = B.shape[0]
-        self._keep = [_f64(L, (d, d)), _f64(B, (nB, d)), _f64(E_sqrtm, (d, d)), _f64(R_sqrtm, (nB, nB)),
-                      _f64(Gamma, (d, d))]
-        desc = FilterDesc(d, int(num_derivatives), nB, *[_dp(a) for a in self._keep])
+        self._keep = [_f64(L, (d, ds)), _f64(B, (nB, ds)), _f64(E_sqrtm, (d, d)), _f64(R_sqrtm, (nB, nB)),
+                      _f64(Gamma, (ds, ds))]
+        desc = FilterDesc(d, int(num_derivatives), nB, *[_dp(a) for a in self._keep], ds)
+        self.ds = ds
         h = _vp()
         ctx.check(self.lib.pnmol_filter_create(ctx.handle, ctypes.byref(desc), ctypes.byref(h)), "pnmol_filter_create")
         self.handle = h
@@ -185,7 +187,7 @@ class Filter:
         return out
 
     def set_operator(self, M, shift=None):
-        a = _f64(M, (self.d, self.d))
+        a = _f64(M, (self.d, self.ds))
         b = _f64(shift, (self.d,)) if shift is not None else None
         self.ctx.check(self.lib.pnmol_filter_set_operator(self.handle, _dp(a), _dp(b) if b is not None else None),
                        "pnmol_filter_set_operator")
@@ -262,8 +264,8 @@ class State:
 
     def set(self, t, mean_nd, cov_DD):
         f = self.filter
-        D = f.n * f.d
-        a, b = _f64(mean_nd, (f.n, f.d)), _f64(cov_DD, (D, D))
+        D = f.n * f.ds
+        a, b = _f64(mean_nd, (f.n, f.ds)), _f64(cov_DD, (D, D))
         self.ctx.check(self.lib.pnmol_state_set(self.handle, float(t), _dp(a), _dp(b)), "pnmol_state_set")
 
     @property
@@ -273,17 +275,17 @@ class State:
         return t.value
 
     def mean(self):
-        out = np.empty((self.filter.n, self.filter.d))
+        out = np.empty((self.filter.n, self.filter.ds))
         self.ctx.check(self.lib.pnmol_state_get_mean(self.handle, _dp(out)), "pnmol_state_get_mean")
         return out
 
     def marginal_var(self):
-        out = np.empty((self.filter.n, self.filter.d))
+        out = np.empty((self.filter.n, self.filter.ds))
         self.ctx.check(self.lib.pnmol_state_get_marginal_var(self.handle, _dp(out)), "pnmol_state_get_marginal_var")
         return out
 
     def cov(self):
-        D = self.filter.n * self.filter.d
+        D = self.filter.n * self.filter.ds
         out = np.empty((D, D))
         self.ctx.check(self.lib.pnmol_state_get_cov(self.handle, _dp(out)), "pnmol_state_get_cov")
         return out

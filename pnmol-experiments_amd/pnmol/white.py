@@ -193,8 +193,9 @@ class _WhiteNoiseEK1Base(pdefilter.PDEFilter):
             t = t + dt
             ts.append(t)
             dt = min(dt0, pde.tmax - t)
-        means = [state.y.mean[0]]
-        stds = [np.sqrt(np.maximum(state.y.marginal_var[0], 0.0))]
+        d = pde.L.shape[0]                                      # (the latent-force state carries eps behind u)
+        means = [state.y.mean[0][:d]]
+        stds = [np.sqrt(np.maximum(state.y.marginal_var[0][:d], 0.0))]
         sig = []
         i = 0
         while i < len(dts):                                     # runs of equal dt -> one device call each
@@ -208,7 +209,7 @@ class _WhiteNoiseEK1Base(pdefilter.PDEFilter):
             i = j
         m_final = dev.mean()
         final = pdefilter.PDEFilterState(t=ts[-1], y=rv.DeviceMultivariateNormal(m_final, dev), error_estimate=None,
-                                         reference_state=np.abs(m_final[0]),
+                                         reference_state=np.abs(m_final[0][:d]),
                                          diffusion_squared_local=sig[-1] if sig else [])
         return np.array(ts), np.array(means), np.array(stds), np.array(sig), final
 
