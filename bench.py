@@ -89,7 +89,10 @@ def main():
     ap.add_argument("--problems-per-gpu", type=int, default=1,
                     help="independent problems run concurrently on each GPU (one context/stream and host thread each); "
                          "the headline metric uses 1")
+    ap.add_argument("--mesh-n", type=int, default=MESH_N,
+                    help="secondary measurement points (BASELINE configs 256 / 1024); the headline metric is 512")
     args = ap.parse_args()
+    globals()["MESH_N"] = args.mesh_n
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -173,11 +176,12 @@ def main():
         achieved = flops / (step_ms_dev * 1e-3) / 1e12
         traffic = None
         try:   # HBM bytes per step from the committed PMC profile (rocprofv3 cannot run inside this process)
-            traffic = json.load(open(ROOT / "profiles" / "traffic.json"))["hbm_bytes_per_step"]
+            if MESH_N == 512:
+                traffic = json.load(open(ROOT / "profiles" / "traffic.json"))["hbm_bytes_per_step"]
         except Exception:
             pass
         line = {
-            "metric": "filter steps/sec, 1D heat N=512 nu=2 (white-noise EK1 predict+update)",
+            "metric": f"filter steps/sec, 1D heat N={MESH_N} nu={NU} (white-noise EK1 predict+update)",
             "value": steps_per_s, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -187,7 +191,7 @@ def main():
                        "device_ms_per_step": step_ms_dev},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
-                         "note": "unit = one filter step (the 26-kernel graph of one predict+update): F_alg = %.4g "
+                         "note": "unit = one filter step (the kernel graph of one predict+update): F_alg = %.4g "
                                  "flop/step (SURVEY 8d), duration = HIP events on the launch stream / steps; "
                                  "traffic = HBM bytes/step from profiles/ (PMC), B_alg = %.3g" % (flops, 3 * D * D * 8)},
         }
