@@ -111,12 +111,14 @@ __global__ __launch_bounds__(256) void k_predict(const double* __restrict__ Pin,
                                                  const double* __restrict__ Kg, IwpConsts c, int dp,
                                                  const double* __restrict__ min, double* __restrict__ mpred,
                                                  const double* __restrict__ shift, double* __restrict__ G,
-                                                 double* __restrict__ zbuf, MeasModel mm, int* __restrict__ ctr) {
+                                                 double* __restrict__ zbuf, MeasModel mm, int* __restrict__ ctr,
+                                                 int* __restrict__ flags, int nflags) {
     const long Dp = (long)N * dp;
     if (blockIdx.y == 0) {  // dispatched first, so its short dependent-load chain hides behind the tile blocks
         if (blockIdx.x != 0) return;
         extern __shared__ double mpl[];  // predicted mean, Dp doubles
         const int tid = threadIdx.y * 32 + threadIdx.x;
+        for (int e = tid; e < nflags; e += 256) flags[e] = 0;  // dependency flags of this step's k_sweep
         for (int j = tid; j < dp; j += 256) {
             double x[N];
 #pragma unroll
@@ -443,14 +445,17 @@ __device__ __forceinline__ void diag2w_inverse_all(double (&u)[NB / 2], Diag2wLd
 
 // Called by waves 0 and 1 of a workgroup (wave = 0/1) after T holds the symmetric tile and a __syncthreads() that
 // also covers the zeroing of L->flag.  Writes L (upper zeroed) to Fd (leading dim ld) and L^-1 to Li (32x32).
+// `sdiag_blk` = the 32 original diagonal entries of this block.  WT: L^-1 is read by OTHER workgroups of the same
+// launch (k_sweep), so it leaves through agent-scope (write-through) stores.
+template <bool WT = false>
 __device__ __forceinline__ void diag2w_from_lds(const double* T, double* __restrict__ Fd, long ld,
                                                 double* __restrict__ Li, int wave, int lane, int* info, int base,
-                                                const double* __restrict__ sdiag, double smax, Diag2wLds* L) {
+                                                const double* sdiag_blk, double smax, Diag2wLds* L) {
     const int i = lane & 31, h = lane >> 5;
     const int pi_i = 16 * (i & 1) + (i >> 1);
     double u[NB / 2];
     if (wave == 0) {
-        const double sdv = fabs(sdiag[base + i]);
+        const double sdv = fabs(sdiag_blk[i]);
         const double thrv = 1e-13 * sdv;
 #pragma unroll
         for (int q = 0; q < NB / 2; ++q) u[q] = T[i * TLD + 2 * q + h];
@@ -476,7 +481,10 @@ __device__ __forceinline__ void diag2w_from_lds(const double* T, double* __restr
         for (int q = 0; q < NB / 2; ++q) u[q] = (2 * q + h == i) ? 1.0 : 0.0;
         diag2w_inverse_all(u, L, lane, pi_i, std::make_integer_sequence<int, NB>{});
 #pragma unroll
-        for (int q = 0; q < NB / 2; ++q) Li[(2 * q + h) * NB + i] = u[q];  // u[q] = Y[i][2q+h] = Linv[2q+h][i]
+        for (int q = 0; q < NB / 2; ++q) {  // u[q] = Y[i][2q+h] = Linv[2q+h][i]
+            if constexpr (WT) __hip_atomic_store(&Li[(2 * q + h) * NB + i], u[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else Li[(2 * q + h) * NB + i] = u[q];
+        }
     }
 }
 
@@ -657,7 +665,328 @@ __global__ __launch_bounds__(256) void k_panel(double* __restrict__ G, double* _
     __syncthreads();
     if (w < 2)  // waves 0 and 1: factor / inverse (two-wave scheme above)
         diag2w_from_lds(sA, F + ((long)(j + 1) * NB) * ld + (long)(j + 1) * NB, ld, Linv + (long)(j + 1) * NB * NB, w, l,
-                        info_base + (*ctr - 1), (j + 1) * NB, sdiag, sdiag[ld], dlp);
+                        info_base + (*ctr - 1), (j + 1) * NB, sdiag + (j + 1) * NB, sdiag[ld], dlp);
+}
+
+// ------------------------------------------------------------------------------------------
+// K3'  The whole sweep  G = [S; P-H^T; z^T; I]  ->  F = [Ls; W; r^T; Ls^-T]  in ONE launch (dataflow, left-looking).
+//
+// One workgroup per 32-row block I of the tall matrix (grid = RT), dependencies pass through global memory:
+//   row[I]  = number of tiles L_I0 .. of row block I published (chain rows only),
+//   diag[I] = 1 once L_II^-1 is published (and row I is complete).
+// Step j of row block I:   S_j = G_Ij - sum_{k<j} X_k L_jk^T   (needs row j of L;  X_k = F_Ik, own row)
+//                          X_j = S_j L_jj^-T                    (needs diag[j])
+// Chain rows (I < CB, the rows of S) stop at j = I-1, keep D = G_II - sum X_k X_k^T in registers and then factorise
+// D with the two-wave scheme above; the other rows (P-H^T, z, identity) run all CB steps.  G is only read.
+// Only  diag[j] -> (load L_jj^-1, two 8-MFMA products) -> factor(j+1) -> diag[j+1]  is on the critical path:
+// everything that needs only row j of L (published BEFORE block j is factorised) happens while block j is being
+// factorised, so a panel costs the 32x32 factorisation + one flag hop (~1.2 us, tools/flag_hop_bench.hip) instead of
+// a kernel boundary + a cold reload of the tiles.
+// Coherence protocol (measured in tools/flag_hop_bench.hip; the XCDs' L2s are not coherent with each other):
+// producers write shared tiles with agent-scope (write-through, sc1) stores, wait for them (s_waitcnt) and then set
+// the flag; consumers poll with agent-scope loads and execute an agent-scope acquire fence (buffer_inv sc1) before
+// touching the data.  A dependency always points to a LOWER block index, and workgroups are dispatched in index
+// order, so waiting cannot deadlock; all spins are bounded anyway (then `info` = -2 and every workgroup bails out).
+// ------------------------------------------------------------------------------------------
+constexpr int SWEEP_SPIN_LIMIT = 1 << 18;
+#ifdef PNMOL_SWEEP_STAMP
+__device__ long long pnmol_sweep_stamp[512][8];
+#define SWEEP_STAMP(slot) do { if (tid == 0) pnmol_sweep_stamp[blockIdx.x][slot] = wall_clock64(); } while (0)
+#define SWEEP_STAMP_L(slot) do { if (l == 0) pnmol_sweep_stamp[blockIdx.x][slot] = wall_clock64(); } while (0)
+// per-step trace of ONE workgroup (block PNMOL_SWEEP_TRACE_WG): rows 256 + j
+#ifndef PNMOL_SWEEP_TRACE_WG
+#define PNMOL_SWEEP_TRACE_WG 16
+#endif
+#define SWEEP_TRACE(j, slot) do { if (tid == 0 && blockIdx.x == PNMOL_SWEEP_TRACE_WG) pnmol_sweep_stamp[256 + (j)][slot] = wall_clock64(); } while (0)
+#else
+#define SWEEP_TRACE(j, slot) do {} while (0)
+#define SWEEP_STAMP(slot) do {} while (0)
+#define SWEEP_STAMP_L(slot) do {} while (0)
+#endif
+
+struct SweepLds {
+    double sS[2][NB * TLD];  // S_j (ping-pong by step parity), C layout; sS[0] is the diagonal tile at the end
+    double sX[NB * TLD];     // X_j of the last step
+    double sP[4][NB * TLD];  // per-wave partial sums of the k-split products; the factorisation's scratch at the end
+    double sd[NB];           // |S_ii| of this block
+    double red[4];
+    int seen[3];             // row[j], row[j+1], diag[j] as last polled
+    int dead, pub;
+};
+static_assert(sizeof(Diag2wLds) <= 4 * NB * TLD * sizeof(double), "Diag2wLds must fit in sP");
+
+__device__ __forceinline__ int flag_ld(const int* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void flag_st(int* p, int v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void wt_st(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// all of this wave's outstanding memory operations (in particular its write-through stores) are complete
+__device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+
+// What a workgroup knows about the three flags step j depends on (uniform per-thread copies of SweepLds::seen).
+struct SweepSeen {
+    int rowj, rown, diag;
+};
+
+// Wait until  row[j] >= need_rowj,  row[j+1] >= need_rown  and  (need_diag ? diag[j] : true).  All three flags are
+// polled together, so a workgroup that lags behind the chain pays one memory round trip per step, not three.
+// Called by all threads.
+__device__ __forceinline__ void sweep_wait(SweepLds* L, const int* frow, const int* fdiag, int* fabort, int j, int jn_ok,
+                                           int need_rowj, int need_rown, bool need_diag, SweepSeen& sn, int tid) {
+    if (sn.rowj >= need_rowj && sn.rown >= need_rown && (!need_diag || sn.diag)) return;
+    __syncthreads();  // every thread has consumed the previous values
+    if (tid == 0) {
+        int r = sn.rowj, rn = sn.rown, d = sn.diag;
+        if (!L->dead) {
+            for (int spins = 0;; ++spins) {
+                r = flag_ld(frow + j);
+                rn = jn_ok ? flag_ld(frow + j + 1) : (1 << 30);
+                d = flag_ld(fdiag + j);
+                if (r >= need_rowj && rn >= need_rown && (!need_diag || d)) break;
+                if (spins > SWEEP_SPIN_LIMIT || flag_ld(fabort)) {
+                    L->dead = 1;
+                    flag_st(fabort, 1);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        if (L->dead) r = rn = 1 << 30, d = 1;  // stop waiting; the step is reported as failed through `info`
+#ifdef PNMOL_SWEEP_INV_EVERY_POLL
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+        L->seen[0] = r;
+        L->seen[1] = rn;
+        L->seen[2] = d;
+    }
+    __syncthreads();
+    sn.rowj = L->seen[0];
+    sn.rown = L->seen[1];
+    sn.diag = L->seen[2];
+}
+
+// MFMA operand fragments straight from global memory.  The inner (k) index of the 16x16x4 MFMA is permuted: step s,
+// lane group g = lane >> 4 takes column 8 g + s, so a lane reads 8 CONTIGUOUS doubles of its row (four 16-byte
+// loads) instead of 8 strided ones; A and B use the same permutation, so the sum is the same set of products.
+struct Frag8 {
+    double v[8];
+};
+__device__ __forceinline__ void frag_ld(Frag8& f, const double* __restrict__ p /* &T[row][8 g], 16-byte aligned */) {
+    const double2* q = reinterpret_cast<const double2*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const double2 t = q[e];
+        f.v[2 * e] = t.x;
+        f.v[2 * e + 1] = t.y;
+    }
+}
+// one 32x32 tile as two row-halves of fragments: rows (l & 15) and 16 + (l & 15)
+struct FragTile {
+    Frag8 lo, hi;
+};
+__device__ __forceinline__ void tile_ld(FragTile& t, const double* __restrict__ p, long ld) {
+    frag_ld(t.lo, p);
+    frag_ld(t.hi, p + 16 * ld);
+}
+
+__global__ __launch_bounds__(256) void k_sweep(const double* __restrict__ G, double* F, double* Linv, int ld, int CB,
+                                               int* flags, int* info_base, const int* __restrict__ ctr) {
+    __shared__ __attribute__((aligned(16))) SweepLds L;
+    const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);  // w: wave-uniform (SGPR)
+    const int wr = w >> 1, wc = w & 1, fr = l & 15, fk = l >> 4;
+    const int I = blockIdx.x;
+    const bool chain = I < CB;
+    int* frow = flags;
+    int* fdiag = flags + CB;
+    int* fabort = flags + 2 * CB;
+    int* info = info_base + (*ctr - 1);
+
+    double smax = 0.0;
+    if (chain) {
+        for (int e = tid; e < ld; e += 256) smax = fmax(smax, fabs(G[(long)e * ld + e]));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) smax = fmax(smax, __shfl_xor(smax, o));
+        if (l == 0) L.red[w] = smax;
+        if (tid < NB) L.sd[tid] = G[(long)(I * NB + tid) * ld + I * NB + tid];
+    }
+    if (tid == 0) {
+        L.dead = 0, L.pub = 0;
+        // One invalidate per workgroup: no copy of F / Linv from before this launch survives in this CU's L1 or this
+        // XCD's L2.  Afterwards a tile is only ever read AFTER its producer's flag (first touch is fresh: tiles are
+        // written once per launch, cache-line aligned, never read speculatively), so no further invalidates are needed
+        // and the shared L tiles stay L2-resident per XCD instead of being re-fetched from memory by every workgroup.
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    SWEEP_STAMP(0);
+    if (chain) smax = fmax(fmax(L.red[0], L.red[1]), fmax(L.red[2], L.red[3]));
+
+    const long rowC = (long)I * NB + wr * 16 + fk;  // first of my four C-layout rows (stride 4)
+    const int colC = wc * 16 + fr;
+    const int offC = (wr * 16 + fk) * TLD + colC;   // the same position in an LDS tile (rows stride 4 * TLD)
+    const double* Xown = F + ((long)I * NB + fr) * ld + 8 * fk;  // A fragments of my own row block: X_k = F[I][k]
+    d4 accD = {0, 0, 0, 0};
+    if (chain) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accD[r] = G[(rowC + 4 * r) * ld + (long)I * NB + colC];
+    }
+
+    const int nsteps = chain ? I : CB;
+    d4 gnext = {0, 0, 0, 0};  // G_{I,j} for the coming step
+    if (nsteps > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gnext[r] = G[(rowC + 4 * r) * ld + colC];
+    }
+    SweepSeen sn{0, 0, 0};
+    for (int j = 0; j < nsteps; ++j) {
+        const int jn_ok = (j + 1 < CB);
+        // (1) S_j = G_Ij - [k-split partial sums over k < j-1, made during step j-1] - X_{j-1} L_{j,j-1}^T
+        d4 acc = gnext;
+        SWEEP_TRACE(j, 0);
+        if (j >= 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[r] -= (L.sP[0][offC + 4 * r * TLD] + L.sP[1][offC + 4 * r * TLD]) +
+                          (L.sP[2][offC + 4 * r * TLD] + L.sP[3][offC + 4 * r * TLD]);
+        }
+        if (j >= 1) {  // newest tile L_{j,j-1}; X_{j-1} is still in LDS
+            sweep_wait(&L, frow, fdiag, fabort, j, jn_ok, j, 0, false, sn, tid);
+            SWEEP_TRACE(j, 1);
+            Frag8 b0;
+            frag_ld(b0, F + ((long)j * NB + wc * 16 + fr) * ld + (long)(j - 1) * NB + 8 * fk);
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-L.sX[(wr * 16 + fr) * TLD + 8 * fk + s], b0.v[s], acc, 0, 0, 0);
+        }
+        double* sS = L.sS[j & 1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sS[offC + 4 * r * TLD] = acc[r];
+        drain_vmem();  // my X stores of the previous step are complete (for the other waves' reads)
+        __syncthreads();
+        SWEEP_TRACE(j, 2);
+        // (2) while the chain catches up: the part of step j+1 that needs only rows published so far,
+        //     sum_{k<j} X_k L_{j+1,k}^T, k split over the four waves (each wave: full 32x32 tile, every 4th k)
+        if (j + 1 < nsteps) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gnext[r] = G[(rowC + 4 * r) * ld + (long)(j + 1) * NB + colC];
+            if (j >= 1) {
+                sweep_wait(&L, frow, fdiag, fabort, j, jn_ok, 0, j, false, sn, tid);
+                SWEEP_TRACE(j, 3);
+                d4 p00 = {0, 0, 0, 0}, p01 = p00, p10 = p00, p11 = p00;
+                const double* Lnext = F + ((long)(j + 1) * NB + fr) * ld + 8 * fk;
+                FragTile a0, b0, a1, b1;  // ping-pong: no register copies, so the loads of tile k+4 stay in flight
+                auto mfma32 = [&](const FragTile& a, const FragTile& b) {
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {
+                        p00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.lo.v[s], b.lo.v[s], p00, 0, 0, 0);
+                        p01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.lo.v[s], b.hi.v[s], p01, 0, 0, 0);
+                        p10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.hi.v[s], b.lo.v[s], p10, 0, 0, 0);
+                        p11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.hi.v[s], b.hi.v[s], p11, 0, 0, 0);
+                    }
+                };
+                // my tiles: k_t = w + 4 t, t < nk.  Loads are unconditional (clamped index) so that the wait counts are
+                // static and the loads of the next tile stay in flight behind the 32 MFMAs of the current one.
+                const int nk = (w < j) ? (j - w + 3) >> 2 : 0;
+                if (nk > 0) {
+                    tile_ld(a0, Xown + (long)w * NB, ld);
+                    tile_ld(b0, Lnext + (long)w * NB, ld);
+                }
+                int t = 0;
+                for (; t + 2 <= nk; t += 2) {
+                    const long k1 = w + 4 * (t + 1), k2 = w + 4 * (t + 2 < nk ? t + 2 : nk - 1);
+                    tile_ld(a1, Xown + k1 * NB, ld);
+                    tile_ld(b1, Lnext + k1 * NB, ld);
+                    mfma32(a0, b0);
+                    tile_ld(a0, Xown + k2 * NB, ld);
+                    tile_ld(b0, Lnext + k2 * NB, ld);
+                    mfma32(a1, b1);
+                }
+                if (t < nk) mfma32(a0, b0);
+                double* sp = L.sP[w];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    sp[(fk + 4 * r) * TLD + fr] = p00[r];
+                    sp[(fk + 4 * r) * TLD + 16 + fr] = p01[r];
+                    sp[(16 + fk + 4 * r) * TLD + fr] = p10[r];
+                    sp[(16 + fk + 4 * r) * TLD + 16 + fr] = p11[r];
+                }
+            }
+        }
+        if (j + 1 == nsteps) SWEEP_STAMP(1);
+        SWEEP_TRACE(j, 4);
+        // (3) X_j = S_j L_jj^-T
+        sweep_wait(&L, frow, fdiag, fabort, j, jn_ok, 0, 0, true, sn, tid);
+        SWEEP_TRACE(j, 5);
+        if (j + 1 == nsteps) SWEEP_STAMP(2);
+        Frag8 bl;
+        frag_ld(bl, Linv + (long)j * NB * NB + (wc * 16 + fr) * NB + 8 * fk);
+        d4 x = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            x = __builtin_amdgcn_mfma_f64_16x16x4f64(sS[(wr * 16 + fr) * TLD + 8 * fk + s], bl.v[s], x, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) L.sX[offC + 4 * r * TLD] = x[r];
+        sn = SweepSeen{sn.rown, 0, 0};  // flags of step j+1: row[j+1] is already known this far
+        if (!chain) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wt_st(&F[(rowC + 4 * r) * ld + (long)j * NB + colC], x[r]);
+            __syncthreads();  // sX and sP complete for the next step
+            if (j + 1 == nsteps && tid == 0 && L.dead) atomicMin(info, -2);
+            if (j + 1 == nsteps) SWEEP_STAMP(5);
+            continue;
+        }
+        __syncthreads();
+        if (w == 3) {  // one wave publishes the tile; the stores complete behind the MFMAs below
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int idx = l + 64 * e, row = idx >> 5, col = idx & 31;
+                wt_st(&F[((long)I * NB + row) * ld + (long)j * NB + col], L.sX[row * TLD + col]);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            accD = __builtin_amdgcn_mfma_f64_16x16x4f64(-L.sX[(wr * 16 + fr) * TLD + 8 * fk + s],
+                                                        L.sX[(wc * 16 + fr) * TLD + 8 * fk + s], accD, 0, 0, 0);
+        if (j + 1 < nsteps && w == 3) {
+            drain_vmem();
+            if (l == 0) flag_st(frow + I, j + 1);
+        }
+        SWEEP_TRACE(j, 6);
+    }
+    if (!chain) return;
+
+    // block (I, I): factorise, publish L_II^-1
+    double* sT = L.sS[0];
+    Diag2wLds* dl = reinterpret_cast<Diag2wLds*>(&L.sP[0][0]);
+    __syncthreads();  // the last step's reads of sS / sP are done
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sT[offC + 4 * r * TLD] = accD[r];
+    if (tid < NB) dl->flag[tid] = 0;
+    __syncthreads();
+    SWEEP_STAMP(3);
+    if (w < 2) {
+        diag2w_from_lds<true>(sT, F + ((long)I * NB) * ld + (long)I * NB, ld, Linv + (long)I * NB * NB, w, l, info,
+                              I * NB, L.sd, smax, dl);
+        if (w == 1) {
+            drain_vmem();  // L^-1 has reached memory
+            if (I > 0) {
+                int spins = 0;
+                while (__hip_atomic_load(&L.pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0 && ++spins < (1 << 24))
+                    __builtin_amdgcn_s_sleep(1);
+            }
+            if (l == 0) flag_st(fdiag + I, 1);
+            SWEEP_STAMP_L(4);
+        }
+    } else if (w == 3 && I > 0) {
+        drain_vmem();  // the last tile of row I has reached memory
+        if (l == 0) flag_st(frow + I, I);
+        __hip_atomic_store(&L.pub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (tid == 0 && L.dead) atomicMin(info, -2);
 }
 
 // One wave per row of four matrix-vector products that all need the finished sweep (role of the extra
@@ -937,6 +1266,8 @@ struct pnmol_ctx {
 struct pnmol_filter {
     pnmol_ctx* ctx = nullptr;
     int d = 0, n = 0, nu = 0, nB = 0, m = 0, dp = 0, mp = 0, CB = 0, RBS = 0, RBW = 0, RT = 0, ellw = 0;
+    int* flags = nullptr;  // k_sweep dependency flags: row[CB], diag[CB], abort
+    int sweep_mode = 1;    // 1: k_sweep (one dataflow launch); 0: k_diag0 + one k_panel launch per panel (PNMOL_HIP_SWEEP=0)
     int ds = 0;  // spatial components of the state (= d, or 2d for the latent-force model [u; eps])
     long Dp = 0;
     IwpConsts iwp{};
@@ -1004,15 +1335,20 @@ int launch_step(pnmol_filter* f, const double* Pin, const double* min, double fr
 
     // K1: P- = A P A^T + Q  (+ one workgroup: m-, z, step counter)
     k_predict<N><<<dim3(dp / 32, dp / 8 + 1), dim3(32, 8), sizeof(double) * Dp, st>>>(
-        Pin, f->Ppred, f->Kg, c, dp, min, f->mpred, f->shift, f->G, f->zbuf, mm, f->ctr);
+        Pin, f->Ppred, f->Kg, c, dp, min, f->mpred, f->shift, f->G, f->zbuf, mm, f->ctr, f->flags, 2 * f->CB + 1);
     // K2: G = [S; P-H^T; z; I] and the first diagonal block
     k_front<<<dim3((mp + 255) / 256, (unsigned)(Dp + 2 * mp)), 256, 0, st>>>(f->Ppred, f->G, f->rdiag, f->Rdense, mm, Dp);
-    k_diag0<<<1, 128, 0, st>>>(f->G, f->F, f->Linv, mp, f->info, f->sdiag, f->ctr);
-    // K3: right-looking sweep, one launch per 32-column panel
-    for (int j = 0; j < f->CB; ++j) {
-        const int nrb = f->RT - (j + 1);
-        const int ncb = f->CB - 1 - j > 0 ? f->CB - 1 - j : 1;
-        k_panel<<<dim3(nrb, ncb), 256, 0, st>>>(f->G, f->F, f->Linv, mp, j, f->CB, f->RBS, f->info, f->sdiag, f->ctr);
+    if (f->sweep_mode == 1) {
+        // K3': the whole sweep as one dataflow launch (one workgroup per 32-row block)
+        k_sweep<<<f->RT, 256, 0, st>>>(f->G, f->F, f->Linv, mp, f->CB, f->flags, f->info, f->ctr);
+    } else {
+        k_diag0<<<1, 128, 0, st>>>(f->G, f->F, f->Linv, mp, f->info, f->sdiag, f->ctr);
+        // K3: right-looking sweep, one launch per 32-column panel
+        for (int j = 0; j < f->CB; ++j) {
+            const int nrb = f->RT - (j + 1);
+            const int ncb = f->CB - 1 - j > 0 ? f->CB - 1 - j : 1;
+            k_panel<<<dim3(nrb, ncb), 256, 0, st>>>(f->G, f->F, f->Linv, mp, j, f->CB, f->RBS, f->info, f->sdiag, f->ctr);
+        }
     }
     // K4: P = P- - W W^T (tiles) and, in extra blockIdx.y rows of the same launch, the vector ops
     const long rowI0 = (long)mp + Dp + NB;
@@ -1320,6 +1656,9 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
     FCHK(hipMalloc(&f->ctr, sizeof(int)));
     if (const char* gc = std::getenv("PNMOL_HIP_GRAPH_CHUNK")) f->graph_chunk = std::atoi(gc) / 2 * 2;
     FCHK(hipMalloc(&f->sdiag, sizeof(double) * (mp + 1)));
+    FCHK(hipMalloc(&f->flags, sizeof(int) * (2 * f->CB + 1)));
+    FCHK(hipMemset(f->flags, 0, sizeof(int) * (2 * f->CB + 1)));
+    if (const char* e = std::getenv("PNMOL_HIP_SWEEP")) f->sweep_mode = std::atoi(e) != 0;
     FCHK(hipMemcpy(f->ell_col, ecol.data(), sizeof(int) * ecol.size(), hipMemcpyHostToDevice));
     FCHK(hipMemcpy(f->ell_val, eval.data(), sizeof(double) * eval.size(), hipMemcpyHostToDevice));
     FCHK(hipMemcpy(f->Kg, Kg.data(), sizeof(double) * Kg.size(), hipMemcpyHostToDevice));
@@ -1350,7 +1689,7 @@ int pnmol_filter_destroy(pnmol_filter* f) {
     if (f->h_pin) hipHostFree(f->h_pin);
     void* ptrs[] = {f->ell_col, f->ell_val, f->Kg,   f->rdiag,   f->Rdense, f->shift,     f->G,        f->F,
                     f->Linv,    f->Ppred,   f->mpred, f->zbuf,   f->var,    f->Sqinv,     f->rec,      f->part,  f->sdiag,
-                    f->info,    f->tmpP,    f->tmpMean, f->rec_means, f->rec_stds};
+                    f->info,    f->tmpP,    f->tmpMean, f->rec_means, f->rec_stds, f->flags};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (f->ev0) hipEventDestroy(f->ev0);
@@ -1596,6 +1935,10 @@ int pnmol_filter_step(pnmol_filter* f, const pnmol_state* in, double dt, pnmol_s
         for (int i = 0; i < f->d; ++i)
             error_estimate_d[i] = have_sq ? dt * std::sqrt(f->sqdiag[i]) * std::sqrt(o.error_sigma2) : std::nan("");
     }
+    if (o.info == -2) {
+        ctx->err = "sweep kernel: a dependency wait timed out (workgroups not co-scheduled?)";
+        return -2;
+    }
     if (o.info >= 0) {
         ctx->err = "innovation matrix not positive definite at pivot " + std::to_string(o.info);
         return -3;
@@ -1693,7 +2036,7 @@ int pnmol_filter_steps_end(pnmol_filter* f, pnmol_state* s, double* means_kd, do
     if (means_kd) std::memcpy(means_kd, hm, sizeof(double) * (size_t)k * f->d);
     if (stds_kd) std::memcpy(stds_kd, hs, sizeof(double) * (size_t)k * f->d);
     const bool have_sq = (f->Sqinv != nullptr && f->sq_dt == dt);
-    int bad = -1;
+    int bad = -1, stuck = -1;
     double t = s->t;
     for (int it = 0; it < k; ++it) {
         t += dt;
@@ -1701,9 +2044,14 @@ int pnmol_filter_steps_end(pnmol_filter* f, pnmol_state* s, double* means_kd, do
         fill_out(f, &rec[(size_t)4 * it], inf[it], t, have_sq, &o);
         if (info_k) info_k[it] = o;
         if (o.info >= 0 && bad < 0) bad = it;
+        if (o.info == -2 && stuck < 0) stuck = it;
     }
     s->t = t;
     s->frame_dt = dt;
+    if (stuck >= 0) {
+        ctx->err = "sweep kernel: a dependency wait timed out in step " + std::to_string(stuck);
+        return -2;
+    }
     if (bad >= 0) {
         ctx->err = "innovation matrix not positive definite in step " + std::to_string(bad);
         return -3;
@@ -1763,6 +2111,15 @@ int pnmol_filter_last_steps_ms(pnmol_filter* f, float* ms) {
 }
 
 int pnmol_filter_debug_read(pnmol_filter* f, int which, double* dst, long count) {
+#ifdef PNMOL_SWEEP_STAMP
+    if (f && which == 5) {
+        hipStreamSynchronize(f->ctx->stream);
+        std::vector<long long> h(512 * 8);
+        if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(pnmol_sweep_stamp), sizeof(long long) * 512 * 8) != hipSuccess) return -2;
+        for (long i = 0; i < count && i < 512 * 8; ++i) dst[i] = (double)h[i];
+        return 0;
+    }
+#endif
     if (!f || !dst || count < 0) return -1;
     pnmol_ctx* ctx = f->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));

@@ -1,0 +1,36 @@
+"""Timeline of one k_sweep launch (library built with -DPNMOL_SWEEP_STAMP, loaded through PNMOL_HIP_LIB)."""
+import sys, pathlib
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "pnmol-experiments_amd"))
+sys.path.insert(0, str(ROOT))
+import numpy as np
+import bench
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+bench.MESH_N = N
+pde, solver = bench.build_problem(0.05, 40)
+state = solver.initialize(pde)
+flt, dev = solver._device_filter, state.y.device_state
+solver._ensure_error_model(pde, bench.DT)
+flt.steps(dev, 20, bench.DT)
+out, info, err = flt.step(dev, bench.DT)     # one eager step: the stamps of its k_sweep
+st = flt.debug_read(5, 512 * 8).reshape(512, 8)
+mp = flt.dims()["mp"]
+CB = mp // 32
+t0 = st[:, 0][st[:, 0] > 0].min()
+us = lambda x: (x - t0) / 100.0
+print("chain WG: start, acc-done(last step), diag-seen, factor-start, published | deltas: wait, trsm+syrk, factor")
+prev = 0.0
+for I in range(CB):
+    a = us(st[I])
+    print(f"I={I:2d} start {a[0]:7.2f} accdone {a[1]:7.2f} diagseen {a[2]:7.2f} fstart {a[3]:7.2f} pub {a[4]:7.2f} | "
+          f"hop {a[2]-prev:5.2f} prep {a[3]-a[2]:5.2f} factor {a[4]-a[3]:5.2f}  panel {a[4]-prev:5.2f}")
+    prev = a[4]
+RT = int((st[:, 0] > 0).sum())
+ends = us(st[CB:RT, 5])
+starts = us(st[CB:RT, 0])
+print(f"bulk WGs {RT-CB}: start min/max {starts.min():.2f}/{starts.max():.2f}  end min/max {ends.min():.2f}/{ends.max():.2f}")
+
+print("per-step trace of WG 16 (us): step-start, row[j] seen, S_j done(barrier), row[j+1] seen, partial done, diag seen, step end")
+for j in range(CB - 1):
+    a = us(st[256 + j])
+    print(f"j={j:2d} " + " ".join(f"{x:8.2f}" for x in a[:7]) + "   | " + " ".join(f"{a[i+1]-a[i]:5.2f}" for i in range(6)))
