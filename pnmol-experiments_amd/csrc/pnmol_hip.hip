@@ -793,17 +793,140 @@ __device__ __forceinline__ void tile_ld(FragTile& t, const double* __restrict__ 
     frag_ld(t.hi, p + 16 * ld);
 }
 
+// Arguments of the covariance down-date role (workgroups RT .. RT + pairs - 1 of a fused launch)
+struct DowndateArgs {
+    const double* Ppred;  // P-  (Dp x Dp)
+    double* Pout;         // P = P- - W W^T
+    double* var;          // diag(P)
+    int dp;               // padded points per derivative (multiple of 32)
+};
+
+// Down-date role: one workgroup per lower pair (J >= K) of 32-point tiles, all N x N derivative blocks.  Wave
+// (qr, qc) owns the 16x16 quadrant (qr, qc) of each block: its accumulators start as the P- tile, every 32-column
+// block j of W is subtracted as soon as the 2 N row blocks of W it needs have published step j (row[] counters), so
+// the down-date rides along with the sweep on CUs the sweep does not use instead of following it.
+template <int N>
+__device__ __forceinline__ void sweep_downdate_role(SweepLds& L, const DowndateArgs& dd, const double* F, int ld, int CB,
+                                                    int RBS, const int* frow, int* fabort, int* info, int pair, int tid,
+                                                    int l, int w) {
+    const int fr = l & 15, fk = l >> 4, qr = w >> 1, qc = w & 1;
+    const int T32 = dd.dp / NB;
+    int J = (int)((sqrt(8.0 * pair + 1.0) - 1.0) * 0.5);  // pair = J (J + 1) / 2 + K
+    while ((J + 1) * (J + 2) / 2 <= pair) ++J;
+    while (J * (J + 1) / 2 > pair) --J;
+    const int K = pair - J * (J + 1) / 2;
+    const long Dp = (long)N * dd.dp;
+    const double* W = F + (long)ld * ld;  // rows of W follow the ld (= mp) rows of Ls
+    d4 acc[N][N];
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+#pragma unroll
+        for (int b = 0; b < N; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[a][b][r] = dd.Ppred[((long)a * dd.dp + J * NB + qr * 16 + fk + 4 * r) * Dp + (long)b * dd.dp + K * NB +
+                                        qc * 16 + fr];
+    int avail = 0;  // column blocks of W known to be complete for all 2 N row blocks
+    for (int j = 0; j < CB; ++j) {
+        if (j >= avail) {
+            __syncthreads();
+            if (w == 0) {
+                int mn = 0;
+                if (!L.dead) {
+                    for (int spins = 0;; ++spins) {
+                        int v = 1 << 30;
+                        if (l < 2 * N) {
+                            const int a = l >> 1, tile = (l & 1) ? K : J;
+                            v = flag_ld(frow + RBS + a * T32 + tile);
+                        }
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+                        mn = v;
+                        if (mn > j) break;
+                        if (spins > SWEEP_SPIN_LIMIT || flag_ld(fabort)) {
+                            if (l == 0) {
+                                L.dead = 1;
+                                flag_st(fabort, 1);
+                            }
+                            mn = 1 << 30;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                } else {
+                    mn = 1 << 30;
+                }
+                if (l == 0) L.seen[0] = mn;
+            }
+            __syncthreads();
+            avail = L.seen[0];
+        }
+        Frag8 fa[N], fb[N];
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            frag_ld(fa[a], W + ((long)a * dd.dp + J * NB + qr * 16 + fr) * ld + (long)j * NB + 8 * fk);
+            frag_ld(fb[a], W + ((long)a * dd.dp + K * NB + qc * 16 + fr) * ld + (long)j * NB + 8 * fk);
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int a = 0; a < N; ++a)
+#pragma unroll
+                for (int b = 0; b < N; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-fa[a].v[s], fb[b].v[s], acc[a][b], 0, 0, 0);
+    }
+    // epilogue: the tile, diag(P), and (J != K) the mirror image, transposed through wave-private LDS so that it
+    // leaves as 128-byte rows
+    double* stg = L.sP[w];
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+#pragma unroll
+        for (int b = 0; b < N; ++b) {
+            const long row0 = (long)a * dd.dp + J * NB + qr * 16, col0 = (long)b * dd.dp + K * NB + qc * 16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double v = acc[a][b][r];
+                dd.Pout[(row0 + fk + 4 * r) * Dp + col0 + fr] = v;
+                if (J == K && a == b && qr == qc && fk + 4 * r == fr) dd.var[row0 + fr] = v;
+                if (J != K) stg[(fk + 4 * r) * 17 + fr] = v;
+            }
+            if (J != K) {
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 4; ++r)  // stg[i][c] = tile(i, c); mirror row c (= fk + 4 r) holds tile(:, c)
+                    dd.Pout[(col0 + fk + 4 * r) * Dp + row0 + fr] = stg[fr * 17 + fk + 4 * r];
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    if (tid == 0 && L.dead) atomicMin(info, -2);
+    SWEEP_STAMP(5);
+}
+
+template <int N, bool FUSED>
 __global__ __launch_bounds__(256) void k_sweep(const double* __restrict__ G, double* F, double* Linv, int ld, int CB,
-                                               int* flags, int* info_base, const int* __restrict__ ctr) {
+                                               int RT, int* flags, int* info_base, const int* __restrict__ ctr,
+                                               DowndateArgs dd) {
     __shared__ __attribute__((aligned(16))) SweepLds L;
     const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);  // w: wave-uniform (SGPR)
     const int wr = w >> 1, wc = w & 1, fr = l & 15, fk = l >> 4;
     const int I = blockIdx.x;
     const bool chain = I < CB;
-    int* frow = flags;
-    int* fdiag = flags + CB;
-    int* fabort = flags + 2 * CB;
+    int* frow = flags;            // [RT]  chain rows: tiles of the row published; other rows: steps completed
+    int* fdiag = flags + RT;      // [CB]
+    int* fabort = flags + RT + CB;
     int* info = info_base + (*ctr - 1);
+    if constexpr (FUSED) {
+        if (I >= RT) {
+            if (tid == 0) {
+                L.dead = 0;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // see the note on the single invalidate below
+            }
+            __syncthreads();
+            SWEEP_STAMP(0);
+            sweep_downdate_role<N>(L, dd, F, ld, CB, CB, frow, fabort, info, I - RT, tid, l, w);
+            return;
+        }
+    }
 
     double smax = 0.0;
     if (chain) {
@@ -931,33 +1054,31 @@ __global__ __launch_bounds__(256) void k_sweep(const double* __restrict__ G, dou
 #pragma unroll
         for (int r = 0; r < 4; ++r) L.sX[offC + 4 * r * TLD] = x[r];
         sn = SweepSeen{sn.rown, 0, 0};  // flags of step j+1: row[j+1] is already known this far
-        if (!chain) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) wt_st(&F[(rowC + 4 * r) * ld + (long)j * NB + colC], x[r]);
-            __syncthreads();  // sX and sP complete for the next step
-            if (j + 1 == nsteps && tid == 0 && L.dead) atomicMin(info, -2);
-            if (j + 1 == nsteps) SWEEP_STAMP(5);
-            continue;
-        }
-        __syncthreads();
-        if (w == 3) {  // one wave publishes the tile; the stores complete behind the MFMAs below
+        __syncthreads();                // sX (and sP) complete
+        if (w == 3) {  // one wave publishes the tile; the stores complete behind the other waves' next instructions
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int idx = l + 64 * e, row = idx >> 5, col = idx & 31;
                 wt_st(&F[((long)I * NB + row) * ld + (long)j * NB + col], L.sX[row * TLD + col]);
             }
         }
+        if (chain) {
 #pragma unroll
-        for (int s = 0; s < 8; ++s)
-            accD = __builtin_amdgcn_mfma_f64_16x16x4f64(-L.sX[(wr * 16 + fr) * TLD + 8 * fk + s],
-                                                        L.sX[(wc * 16 + fr) * TLD + 8 * fk + s], accD, 0, 0, 0);
-        if (j + 1 < nsteps && w == 3) {
+            for (int s = 0; s < 8; ++s)
+                accD = __builtin_amdgcn_mfma_f64_16x16x4f64(-L.sX[(wr * 16 + fr) * TLD + 8 * fk + s],
+                                                            L.sX[(wc * 16 + fr) * TLD + 8 * fk + s], accD, 0, 0, 0);
+        }
+        if ((!chain || j + 1 < nsteps) && w == 3) {  // (a chain row's last tile is published during its factorisation)
             drain_vmem();
             if (l == 0) flag_st(frow + I, j + 1);
         }
         SWEEP_TRACE(j, 6);
     }
-    if (!chain) return;
+    if (!chain) {
+        if (tid == 0 && L.dead) atomicMin(info, -2);
+        SWEEP_STAMP(5);
+        return;
+    }
 
     // block (I, I): factorise, publish L_II^-1
     double* sT = L.sS[0];
@@ -1203,6 +1324,11 @@ __global__ __launch_bounds__(256, (N <= 3 ? 4 : 1)) void k_downdate(const double
         downdate_finish<N, 1>(acc, smem, Ppred, Pout, var, dp, Dp, J, K, l);
 }
 
+// the vector ops of the step as their own launch (fused mode: the down-date rides in k_sweep, so they have no host)
+__global__ __launch_bounds__(256) void k_vecops(const double* __restrict__ W, int mp, long Dp, VecArgs va) {
+    vecops_rows(va, W, mp, Dp, (long)blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+}
+
 // per-step read-out of the parity quantities (experiments/figure1.py:76-80), raw coordinates;
 // block 0 also reduces the partial sums of the vector-op rows into rec[0..2] (fixed order: deterministic)
 __global__ __launch_bounds__(256) void k_readout(const double* __restrict__ mean, const double* __restrict__ var,
@@ -1266,8 +1392,9 @@ struct pnmol_ctx {
 struct pnmol_filter {
     pnmol_ctx* ctx = nullptr;
     int d = 0, n = 0, nu = 0, nB = 0, m = 0, dp = 0, mp = 0, CB = 0, RBS = 0, RBW = 0, RT = 0, ellw = 0;
-    int* flags = nullptr;  // k_sweep dependency flags: row[CB], diag[CB], abort
-    int sweep_mode = 1;    // 1: k_sweep (one dataflow launch); 0: k_diag0 + one k_panel launch per panel (PNMOL_HIP_SWEEP=0)
+    int* flags = nullptr;  // k_sweep dependency flags: row[RT], diag[CB], abort
+    int sweep_mode = 2;    // PNMOL_HIP_SWEEP: 2 = k_sweep with the covariance down-date riding along in the same launch,
+                           // 1 = k_sweep, then k_downdate; 0 = k_diag0 + one k_panel launch per panel, then k_downdate
     int ds = 0;  // spatial components of the state (= d, or 2d for the latent-force model [u; eps])
     long Dp = 0;
     IwpConsts iwp{};
@@ -1335,30 +1462,40 @@ int launch_step(pnmol_filter* f, const double* Pin, const double* min, double fr
 
     // K1: P- = A P A^T + Q  (+ one workgroup: m-, z, step counter)
     k_predict<N><<<dim3(dp / 32, dp / 8 + 1), dim3(32, 8), sizeof(double) * Dp, st>>>(
-        Pin, f->Ppred, f->Kg, c, dp, min, f->mpred, f->shift, f->G, f->zbuf, mm, f->ctr, f->flags, 2 * f->CB + 1);
+        Pin, f->Ppred, f->Kg, c, dp, min, f->mpred, f->shift, f->G, f->zbuf, mm, f->ctr, f->flags, f->RT + f->CB + 1);
     // K2: G = [S; P-H^T; z; I] and the first diagonal block
     k_front<<<dim3((mp + 255) / 256, (unsigned)(Dp + 2 * mp)), 256, 0, st>>>(f->Ppred, f->G, f->rdiag, f->Rdense, mm, Dp);
-    if (f->sweep_mode == 1) {
-        // K3': the whole sweep as one dataflow launch (one workgroup per 32-row block)
-        k_sweep<<<f->RT, 256, 0, st>>>(f->G, f->F, f->Linv, mp, f->CB, f->flags, f->info, f->ctr);
-    } else {
-        k_diag0<<<1, 128, 0, st>>>(f->G, f->F, f->Linv, mp, f->info, f->sdiag, f->ctr);
-        // K3: right-looking sweep, one launch per 32-column panel
-        for (int j = 0; j < f->CB; ++j) {
-            const int nrb = f->RT - (j + 1);
-            const int ncb = f->CB - 1 - j > 0 ? f->CB - 1 - j : 1;
-            k_panel<<<dim3(nrb, ncb), 256, 0, st>>>(f->G, f->F, f->Linv, mp, j, f->CB, f->RBS, f->info, f->sdiag, f->ctr);
-        }
-    }
-    // K4: P = P- - W W^T (tiles) and, in extra blockIdx.y rows of the same launch, the vector ops
     const long rowI0 = (long)mp + Dp + NB;
     const double* W = f->F + (long)mp * mp;
     const bool have_sq = (f->Sqinv != nullptr && f->sq_dt == dt);
     VecArgs va{f->mpred, f->F + ((long)mp + Dp) * mp, f->F + rowI0 * mp, f->zbuf, have_sq ? f->Sqinv : nullptr,
                mout, f->part};
-    const int tiles = dp / 16;
-    const int vrows = (int)(((Dp + mp + 3) / 4 + tiles - 1) / tiles);
-    k_downdate<N><<<dim3(tiles, tiles + vrows), 256, 0, st>>>(f->Ppred, W, Pout, varout, dp, mp, 0, mp / 8, va);
+    DowndateArgs dd{f->Ppred, Pout, varout, dp};
+    if (f->sweep_mode == 2) {
+        // K3'+K4: the whole sweep as one dataflow launch (one workgroup per 32-row block) with the covariance
+        // down-date riding along (one workgroup per pair of 32-point tiles), then the vector ops
+        const int t32 = dp / NB, pairs = t32 * (t32 + 1) / 2;
+        if constexpr (N <= 3)
+            k_sweep<N, true><<<f->RT + pairs, 256, 0, st>>>(f->G, f->F, f->Linv, mp, f->CB, f->RT, f->flags, f->info, f->ctr, dd);
+        k_vecops<<<(unsigned)((Dp + mp + 3) / 4), 256, 0, st>>>(W, mp, Dp, va);
+    } else {
+        if (f->sweep_mode == 1) {
+            // K3': the sweep alone as one dataflow launch
+            k_sweep<N, false><<<f->RT, 256, 0, st>>>(f->G, f->F, f->Linv, mp, f->CB, f->RT, f->flags, f->info, f->ctr, dd);
+        } else {
+            k_diag0<<<1, 128, 0, st>>>(f->G, f->F, f->Linv, mp, f->info, f->sdiag, f->ctr);
+            // K3: right-looking sweep, one launch per 32-column panel
+            for (int j = 0; j < f->CB; ++j) {
+                const int nrb = f->RT - (j + 1);
+                const int ncb = f->CB - 1 - j > 0 ? f->CB - 1 - j : 1;
+                k_panel<<<dim3(nrb, ncb), 256, 0, st>>>(f->G, f->F, f->Linv, mp, j, f->CB, f->RBS, f->info, f->sdiag, f->ctr);
+            }
+        }
+        // K4: P = P- - W W^T (tiles) and, in extra blockIdx.y rows of the same launch, the vector ops
+        const int tiles = dp / 16;
+        const int vrows = (int)(((Dp + mp + 3) / 4 + tiles - 1) / tiles);
+        k_downdate<N><<<dim3(tiles, tiles + vrows), 256, 0, st>>>(f->Ppred, W, Pout, varout, dp, mp, 0, mp / 8, va);
+    }
     // K5: read-out + deterministic reduction of the per-row partial sums
     k_readout<<<(f->d + 255) / 256, 256, 0, st>>>(mout, varout, record ? f->rec_means : nullptr,
                                                   record ? f->rec_stds : nullptr, nordsieck_scale(f->nu, 0, dt), f->d,
@@ -1656,9 +1793,10 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
     FCHK(hipMalloc(&f->ctr, sizeof(int)));
     if (const char* gc = std::getenv("PNMOL_HIP_GRAPH_CHUNK")) f->graph_chunk = std::atoi(gc) / 2 * 2;
     FCHK(hipMalloc(&f->sdiag, sizeof(double) * (mp + 1)));
-    FCHK(hipMalloc(&f->flags, sizeof(int) * (2 * f->CB + 1)));
-    FCHK(hipMemset(f->flags, 0, sizeof(int) * (2 * f->CB + 1)));
-    if (const char* e = std::getenv("PNMOL_HIP_SWEEP")) f->sweep_mode = std::atoi(e) != 0;
+    FCHK(hipMalloc(&f->flags, sizeof(int) * (f->RT + f->CB + 1)));
+    FCHK(hipMemset(f->flags, 0, sizeof(int) * (f->RT + f->CB + 1)));
+    if (const char* e = std::getenv("PNMOL_HIP_SWEEP")) f->sweep_mode = std::atoi(e);
+    if (f->sweep_mode == 2 && n > 3) f->sweep_mode = 1;  // the fused down-date role is built for n <= 3
     FCHK(hipMemcpy(f->ell_col, ecol.data(), sizeof(int) * ecol.size(), hipMemcpyHostToDevice));
     FCHK(hipMemcpy(f->ell_val, eval.data(), sizeof(double) * eval.size(), hipMemcpyHostToDevice));
     FCHK(hipMemcpy(f->Kg, Kg.data(), sizeof(double) * Kg.size(), hipMemcpyHostToDevice));

@@ -25,10 +25,15 @@ for I in range(CB):
     print(f"I={I:2d} start {a[0]:7.2f} accdone {a[1]:7.2f} diagseen {a[2]:7.2f} fstart {a[3]:7.2f} pub {a[4]:7.2f} | "
           f"hop {a[2]-prev:5.2f} prep {a[3]-a[2]:5.2f} factor {a[4]-a[3]:5.2f}  panel {a[4]-prev:5.2f}")
     prev = a[4]
-RT = int((st[:, 0] > 0).sum())
+dp = flt.dims()["dp"]
+RT = 2 * CB + 3 * dp // 32 + 1
 ends = us(st[CB:RT, 5])
 starts = us(st[CB:RT, 0])
 print(f"bulk WGs {RT-CB}: start min/max {starts.min():.2f}/{starts.max():.2f}  end min/max {ends.min():.2f}/{ends.max():.2f}")
+nd = int((st[RT:256, 0] > 0).sum())
+if nd:
+    e2, s2 = us(st[RT:RT + nd, 5]), us(st[RT:RT + nd, 0])
+    print(f"down-date WGs {nd}: start min/max {s2.min():.2f}/{s2.max():.2f}  end min/median/max {e2.min():.2f}/{np.median(e2):.2f}/{e2.max():.2f}")
 
 print("per-step trace of WG 16 (us): step-start, row[j] seen, S_j done(barrier), row[j+1] seen, partial done, diag seen, step end")
 for j in range(CB - 1):
