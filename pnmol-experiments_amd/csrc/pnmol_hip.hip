@@ -691,8 +691,8 @@ __global__ __launch_bounds__(256) void k_panel(double* __restrict__ G, double* _
 constexpr int SWEEP_SPIN_LIMIT = 1 << 18;
 #ifdef PNMOL_SWEEP_STAMP
 __device__ long long pnmol_sweep_stamp[512][8];
-#define SWEEP_STAMP(slot) do { if (tid == 0) pnmol_sweep_stamp[blockIdx.x][slot] = wall_clock64(); } while (0)
-#define SWEEP_STAMP_L(slot) do { if (l == 0) pnmol_sweep_stamp[blockIdx.x][slot] = wall_clock64(); } while (0)
+#define SWEEP_STAMP(slot) do { if (tid == 0 && blockIdx.x < 256) pnmol_sweep_stamp[blockIdx.x][slot] = wall_clock64(); } while (0)
+#define SWEEP_STAMP_L(slot) do { if (l == 0 && blockIdx.x < 256) pnmol_sweep_stamp[blockIdx.x][slot] = wall_clock64(); } while (0)
 // per-step trace of ONE workgroup (block PNMOL_SWEEP_TRACE_WG): rows 256 + j
 #ifndef PNMOL_SWEEP_TRACE_WG
 #define PNMOL_SWEEP_TRACE_WG 16
