@@ -226,3 +226,33 @@ def test_full_size_2d_mesh_properties(hip_ctx):
     assert var.min() > -1e-9 * var.max()
     t2, means2, stds2, sig2, _ = solver.solve_marginals(pde)
     assert np.array_equal(means, means2) and np.array_equal(stds, stds2) and np.array_equal(sig, sig2)
+
+
+def test_concurrent_problems_on_one_gpu():
+    """Several problems in flight on ONE GPU (one context / stream each, `steps_begin` .. `steps_end`): the sweep kernel's
+    workgroups wait for each other through global-memory flags, so kernels of different problems sharing the CUs must
+    neither deadlock nor disturb each other -- every problem must reproduce its own sequential result bit for bit."""
+    import pnmol
+    from pnmol import _hip, batch
+    dt, K, B = 2.0 ** -7, 12, 6
+    runs = []
+    for g in range(B):
+        pde = pnmol.pde.examples.heat_1d_discretized(tmax=K * dt, dx=1.0 / 255, diffusion_rate=batch.diffusion_sweep(g, 8),
+                                                     kernel=pnmol.kernels.SquareExponential(), bcond="dirichlet")
+        solver = pnmol.white.LinearWhiteNoiseEK1(num_derivatives=2, steprule=pnmol.odetools.step.Constant(dt),
+                                                 spatial_kernel=pnmol.kernels.Matern52() + pnmol.kernels.WhiteNoise())
+        solver._context = _hip.Context(0)
+        state = solver.initialize(pde)
+        solver._ensure_error_model(pde, dt)
+        flt, dev = solver._device_filter, state.y.device_state
+        ref = flt.new_state()
+        ref.set(pde.t0, dev.mean(), dev.cov())
+        seq = flt.steps(ref, K, dt)                      # sequential reference, this problem alone on the device
+        runs.append((solver, flt, dev, seq))
+    for _, flt, dev, _ in runs:
+        flt.steps_begin(dev, K, dt)
+    for _, flt, dev, (m_seq, s_seq, i_seq) in runs:
+        m, s, infos = flt.steps_end(dev)
+        assert all(o.info == -1 for o in infos)
+        assert np.array_equal(m, m_seq) and np.array_equal(s, s_seq)
+        assert [o.diffusion_squared_local for o in infos] == [o.diffusion_squared_local for o in i_seq]
