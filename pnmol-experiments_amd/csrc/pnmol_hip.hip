@@ -793,12 +793,118 @@ __device__ __forceinline__ void tile_ld(FragTile& t, const double* __restrict__ 
     frag_ld(t.hi, p + 16 * ld);
 }
 
+// One wave per row of four matrix-vector products that all need the finished sweep (role of the extra
+// blockIdx.y rows of k_downdate):
+//   rows [0, Dp)          m = m- - W r                               (mean update, white.py:123)
+//   rows [Dp, Dp+mp)      part[0][i] = r_i^2                         (whitened residual)
+//                         part[1][i] = (Ls^-T z)_i^2                 (white.py:125 with the Cholesky factor)
+//                         part[2][i] = z_i (Sq^-1 z)_i               (estimate_error, white.py:153-162)
+struct VecArgs {
+    const double* mpred;
+    const double* r;
+    const double* LinvT;
+    const double* z;
+    const double* Sqinv;
+    double* mout;
+    double* part;
+};
+
+__device__ __forceinline__ void vecops_rows(const VecArgs& va, const double* __restrict__ W, int mp, long Dp,
+                                            long wave_row, int l) {
+    const long row = wave_row;
+    if (row < Dp) {
+        double sacc = 0.0;
+        for (int i = l; i < mp; i += 64) sacc += W[row * mp + i] * va.r[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
+        if (l == 0) va.mout[row] = va.mpred[row] - sacc;
+    } else if (row < Dp + mp) {
+        const long q = row - Dp;
+        double x = 0.0, y = 0.0;
+        for (int i = l; i < mp; i += 64) {
+            const double zi = va.z[i];
+            x += va.LinvT[q * mp + i] * zi;
+            if (va.Sqinv) y += va.Sqinv[q * mp + i] * zi;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            x += __shfl_xor(x, o);
+            y += __shfl_xor(y, o);
+        }
+        if (l == 0) {
+            va.part[q] = va.r[q] * va.r[q];
+            va.part[mp + q] = x * x;
+            va.part[2 * mp + q] = va.z[q] * y;
+        }
+    }
+}
+
+// rows [r0, r1), r1 - r0 <= 4, of vecops_rows by one wave; same per-row lane-strided summation, but the loads of up
+// to 4 rows x 4 column slices are issued before the first is used
+__device__ __forceinline__ void vecops_rows4(const VecArgs& va, const double* __restrict__ W, int mp, long Dp, long r0,
+                                             long r1, int l) {
+    double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+    const double* src[4];
+    const double* src2[4];
+    bool isw[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const long row = min(r0 + q, r1 - 1);
+        isw[q] = row < Dp;
+        src[q] = isw[q] ? W + row * mp : va.LinvT + (row - Dp) * mp;
+        src2[q] = (!isw[q] && va.Sqinv) ? va.Sqinv + (row - Dp) * mp : nullptr;
+    }
+    for (int i0 = l; i0 < mp; i0 += 256) {
+        double wv[4][4], sv[4][4], xv[4], zv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int i = i0 + 64 * t;
+            const bool in = i < mp;
+            xv[t] = in ? va.r[i] : 0.0;
+            zv[t] = in ? va.z[i] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                wv[q][t] = in ? src[q][i] : 0.0;
+                sv[q][t] = (in && src2[q]) ? src2[q][i] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                a[q] += wv[q][t] * (isw[q] ? xv[t] : zv[t]);
+                b[q] += sv[q][t] * zv[t];
+            }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            a[q] += __shfl_xor(a[q], o);
+            b[q] += __shfl_xor(b[q], o);
+        }
+        const long row = r0 + q;
+        if (l == 0 && row < r1) {
+            if (row < Dp) {
+                va.mout[row] = va.mpred[row] - a[q];
+            } else if (row < Dp + mp) {
+                const long k = row - Dp;
+                va.part[k] = va.r[k] * va.r[k];
+                va.part[mp + k] = a[q] * a[q];
+                va.part[2 * mp + k] = va.z[k] * b[q];
+            }
+        }
+    }
+}
+
 // Arguments of the covariance down-date role (workgroups RT .. RT + pairs - 1 of a fused launch)
 struct DowndateArgs {
     const double* Ppred;  // P-  (Dp x Dp)
     double* Pout;         // P = P- - W W^T
     double* var;          // diag(P)
     int dp;               // padded points per derivative (multiple of 32)
+    int vrows;            // rows of the vector ops (vecops_rows) each down-date workgroup does at its end
+    VecArgs va;
 };
 
 // Down-date role: one workgroup per lower pair (J >= K) of 32-point tiles, all N x N derivative blocks.  Wave
@@ -898,6 +1004,32 @@ __device__ __forceinline__ void sweep_downdate_role(SweepLds& L, const DowndateA
                 __builtin_amdgcn_wave_barrier();
             }
         }
+    // The vector ops of the step ride at the end of this role (rows [pair * vrows, +vrows) of vecops_rows): by now the
+    // whole sweep is finished or about to be; a row still waits for the row block it reads and for the r^T block.
+    {
+        const int RBW = (int)(Dp / NB);
+        const long row_lo = (long)pair * dd.vrows, row_hi = min(row_lo + dd.vrows, Dp + (long)ld);
+        __syncthreads();
+        if (tid == 0 && !L.dead && row_lo < row_hi) {
+            for (long rb = row_lo / NB; rb <= (row_hi - 1) / NB; ++rb) {  // row blocks of [W; Ls^-T] this range touches
+                const int need = rb < RBW ? RBS + (int)rb : RBS + RBW + 1 + (int)(rb - RBW);
+                for (int spins = 0;; ++spins) {
+                    if (flag_ld(frow + need) >= CB && flag_ld(frow + RBS + RBW) >= CB) break;
+                    if (spins > SWEEP_SPIN_LIMIT || flag_ld(fabort)) {
+                        L.dead = 1;
+                        flag_st(fabort, 1);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (L.dead) break;
+            }
+        }
+        __syncthreads();
+        // four rows per wave at a time with all loads of a slice of columns in flight (this tail is latency-bound:
+        // one workgroup per CU, nothing else to switch to)
+        for (long rg = row_lo + 4 * w; rg < row_hi; rg += 16) vecops_rows4(dd.va, W, ld, Dp, rg, min(rg + 4, row_hi), l);
+    }
     if (tid == 0 && L.dead) atomicMin(info, -2);
     SWEEP_STAMP(5);
 }
@@ -1110,52 +1242,6 @@ __global__ __launch_bounds__(256) void k_sweep(const double* __restrict__ G, dou
     if (tid == 0 && L.dead) atomicMin(info, -2);
 }
 
-// One wave per row of four matrix-vector products that all need the finished sweep (role of the extra
-// blockIdx.y rows of k_downdate):
-//   rows [0, Dp)          m = m- - W r                               (mean update, white.py:123)
-//   rows [Dp, Dp+mp)      part[0][i] = r_i^2                         (whitened residual)
-//                         part[1][i] = (Ls^-T z)_i^2                 (white.py:125 with the Cholesky factor)
-//                         part[2][i] = z_i (Sq^-1 z)_i               (estimate_error, white.py:153-162)
-struct VecArgs {
-    const double* mpred;
-    const double* r;
-    const double* LinvT;
-    const double* z;
-    const double* Sqinv;
-    double* mout;
-    double* part;
-};
-
-__device__ __forceinline__ void vecops_rows(const VecArgs& va, const double* __restrict__ W, int mp, long Dp,
-                                            long wave_row, int l) {
-    const long row = wave_row;
-    if (row < Dp) {
-        double sacc = 0.0;
-        for (int i = l; i < mp; i += 64) sacc += W[row * mp + i] * va.r[i];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
-        if (l == 0) va.mout[row] = va.mpred[row] - sacc;
-    } else if (row < Dp + mp) {
-        const long q = row - Dp;
-        double x = 0.0, y = 0.0;
-        for (int i = l; i < mp; i += 64) {
-            const double zi = va.z[i];
-            x += va.LinvT[q * mp + i] * zi;
-            if (va.Sqinv) y += va.Sqinv[q * mp + i] * zi;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            x += __shfl_xor(x, o);
-            y += __shfl_xor(y, o);
-        }
-        if (l == 0) {
-            va.part[q] = va.r[q] * va.r[q];
-            va.part[mp + q] = x * x;
-            va.part[2 * mp + q] = va.z[q] * y;
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // covariance down-date  P = P- - W W^T  on 16x16 point tiles x all n*n derivative blocks.
 // One workgroup (4 waves) per lower tile pair (J >= K).  The waves split the inner (measurement) dimension
@@ -1324,11 +1410,6 @@ __global__ __launch_bounds__(256, (N <= 3 ? 4 : 1)) void k_downdate(const double
         downdate_finish<N, 1>(acc, smem, Ppred, Pout, var, dp, Dp, J, K, l);
 }
 
-// the vector ops of the step as their own launch (fused mode: the down-date rides in k_sweep, so they have no host)
-__global__ __launch_bounds__(256) void k_vecops(const double* __restrict__ W, int mp, long Dp, VecArgs va) {
-    vecops_rows(va, W, mp, Dp, (long)blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
-}
-
 // per-step read-out of the parity quantities (experiments/figure1.py:76-80), raw coordinates;
 // block 0 also reduces the partial sums of the vector-op rows into rec[0..2] (fixed order: deterministic)
 __global__ __launch_bounds__(256) void k_readout(const double* __restrict__ mean, const double* __restrict__ var,
@@ -1470,14 +1551,14 @@ int launch_step(pnmol_filter* f, const double* Pin, const double* min, double fr
     const bool have_sq = (f->Sqinv != nullptr && f->sq_dt == dt);
     VecArgs va{f->mpred, f->F + ((long)mp + Dp) * mp, f->F + rowI0 * mp, f->zbuf, have_sq ? f->Sqinv : nullptr,
                mout, f->part};
-    DowndateArgs dd{f->Ppred, Pout, varout, dp};
+    DowndateArgs dd{f->Ppred, Pout, varout, dp, 0, va};
     if (f->sweep_mode == 2) {
         // K3'+K4: the whole sweep as one dataflow launch (one workgroup per 32-row block) with the covariance
         // down-date riding along (one workgroup per pair of 32-point tiles), then the vector ops
         const int t32 = dp / NB, pairs = t32 * (t32 + 1) / 2;
+        dd.vrows = (int)((Dp + mp + pairs - 1) / pairs);  // the vector ops ride at the end of the down-date workgroups
         if constexpr (N <= 3)
             k_sweep<N, true><<<f->RT + pairs, 256, 0, st>>>(f->G, f->F, f->Linv, mp, f->CB, f->RT, f->flags, f->info, f->ctr, dd);
-        k_vecops<<<(unsigned)((Dp + mp + 3) / 4), 256, 0, st>>>(W, mp, Dp, va);
     } else {
         if (f->sweep_mode == 1) {
             // K3': the sweep alone as one dataflow launch
