@@ -69,6 +69,11 @@ int pnmol_filter_destroy(pnmol_filter* f);
  * Without it, the error estimate of a step with this dt is reported as NaN. */
 int pnmol_filter_set_error_model(pnmol_filter* f, double dt, const double* Sq_inv,
                                  const double* Sq_diag);
+/* The same on the device, from the operator currently set (L, or J_x + L after `pnmol_filter_set_operator`):
+ * Sq is the innovation matrix of a filter whose predicted covariance is Ql Ql^T = Q1 (x) K, so the step's own
+ * kernels factorise it ([Sq; I] -> [Lq; Lq^-T], Sq^-1 = Lq^-T Lq^-1); diag(Sq) is kept for the error vector.  No host
+ * O(m^3) work per new dt / per semilinear step. */
+int pnmol_filter_prepare_error_model(pnmol_filter* f, double dt);
 
 /* Semilinear EK1 (`SemiLinearWhiteNoiseEK1.evaluate_ode`, white.py:189-208): the measurement rows become
  * H_ode = E1 - (J_x + L) E0 with shift b = J_x m_at - f(t, m_at), re-linearised at every step.

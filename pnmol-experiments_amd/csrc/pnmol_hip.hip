@@ -1410,6 +1410,38 @@ __global__ __launch_bounds__(256, (N <= 3 ? 4 : 1)) void k_downdate(const double
         downdate_finish<N, 1>(acc, smem, Ppred, Pout, var, dp, Dp, J, K, l);
 }
 
+// ------------------------------------------------------------------------------------------
+// On-device error model (estimate_error, white.py:153-162).  Sq = H (Ql Ql^T) H^T + E E^T is the innovation matrix of
+// a filter whose predicted covariance is Q = Q1 (x) K, so the same k_front / k_sweep pair factorises it:
+// [Sq; I] -> [Lq; Lq^-T], and Sq^-1 = Lq^-T Lq^-1.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fill_q(double* __restrict__ Qf, const double* __restrict__ Kg, IwpConsts c, int n,
+                                                int dp) {
+    const long Dp = (long)n * dp;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= Dp * Dp) return;
+    const long row = e / Dp, col = e % Dp;
+    const int a = (int)(row / dp), j = (int)(row % dp), b = (int)(col / dp), k = (int)(col % dp);
+    Qf[e] = c.Q1[a * MAXN + b] * Kg[(long)j * dp + k];
+}
+
+// C = T T^T for a row-major (mp x mp) T (rows dot rows), 16x16 outputs per workgroup
+__global__ __launch_bounds__(256) void k_ttt(const double* __restrict__ T, double* __restrict__ C, int mp) {
+    __shared__ double sa[16][17], sb[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int i = blockIdx.y * 16 + ty, k = blockIdx.x * 16 + tx;
+    double acc = 0.0;
+    for (int q0 = 0; q0 < mp; q0 += 16) {
+        sa[ty][tx] = T[(long)(blockIdx.y * 16 + ty) * mp + q0 + tx];
+        sb[ty][tx] = T[(long)(blockIdx.x * 16 + ty) * mp + q0 + tx];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc += sa[ty][q] * sb[tx][q];
+        __syncthreads();
+    }
+    C[(long)i * mp + k] = acc;
+}
+
 // per-step read-out of the parity quantities (experiments/figure1.py:76-80), raw coordinates;
 // block 0 also reduces the partial sums of the vector-op rows into rec[0..2] (fixed order: deterministic)
 __global__ __launch_bounds__(256) void k_readout(const double* __restrict__ mean, const double* __restrict__ var,
@@ -1486,6 +1518,9 @@ struct pnmol_filter {
     double *var = nullptr, *Sqinv = nullptr, *rec = nullptr, *part = nullptr, *sdiag = nullptr;
     int* info = nullptr;
     std::vector<double> sqdiag;
+    double* Qfull = nullptr;  // Q1 (x) K as a dense Dp x Dp matrix (on-device error model), allocated on first use
+    int* one = nullptr;       // device constant 1 (step-counter stand-in for sweeps outside the step loop)
+    int* info_err = nullptr;  // info word of those sweeps
     double sq_dt = -1.0;
     std::vector<double> hB;   // host copy of pde.B (nB x d) for operator rebuilds
     int ell_cap = 0;          // allocated ELL width
@@ -1712,6 +1747,17 @@ void fill_out(const pnmol_filter* f, const double* rec, int info, double t_new, 
     o->info = (info >= f->mp) ? -1 : info;
 }
 
+template <int N>
+int run_error_model_sweep(pnmol_filter* f, const MeasModel& mm) {
+    hipStream_t st = f->ctx->stream;
+    const int mp = f->mp;
+    const long Dp = f->Dp;
+    k_front<<<dim3((mp + 255) / 256, (unsigned)(Dp + 2 * mp)), 256, 0, st>>>(f->Qfull, f->G, f->rdiag, f->Rdense, mm, Dp);
+    DowndateArgs dd{};
+    k_sweep<N, false><<<f->RT, 256, 0, st>>>(f->G, f->F, f->Linv, mp, f->CB, f->RT, f->flags, f->info_err, f->one, dd);
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1908,7 +1954,7 @@ int pnmol_filter_destroy(pnmol_filter* f) {
     if (f->h_pin) hipHostFree(f->h_pin);
     void* ptrs[] = {f->ell_col, f->ell_val, f->Kg,   f->rdiag,   f->Rdense, f->shift,     f->G,        f->F,
                     f->Linv,    f->Ppred,   f->mpred, f->zbuf,   f->var,    f->Sqinv,     f->rec,      f->part,  f->sdiag,
-                    f->info,    f->tmpP,    f->tmpMean, f->rec_means, f->rec_stds, f->flags};
+                    f->info,    f->tmpP,    f->tmpMean, f->rec_means, f->rec_stds, f->flags, f->Qfull, f->one, f->info_err};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (f->ev0) hipEventDestroy(f->ev0);
@@ -1940,6 +1986,58 @@ int pnmol_filter_set_error_model(pnmol_filter* f, double dt, const double* Sq_in
     f->sqdiag.assign(Sq_diag, Sq_diag + m);
     f->sq_dt = dt;
     drop_graphs(f);
+    return 0;
+}
+
+int pnmol_filter_prepare_error_model(pnmol_filter* f, double dt) {
+    if (!f || !(dt > 0.0)) return -1;
+    pnmol_ctx* ctx = f->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int mp = f->mp, m = f->m, dp = f->dp;
+    const long Dp = f->Dp;
+    if (!f->Qfull) {
+        HIPCHK(ctx, hipMalloc(&f->Qfull, sizeof(double) * (size_t)Dp * Dp));
+        HIPCHK(ctx, hipMalloc(&f->one, sizeof(int)));
+        HIPCHK(ctx, hipMalloc(&f->info_err, sizeof(int)));
+        const int h1 = 1;
+        HIPCHK(ctx, hipMemcpy(f->one, &h1, sizeof(int), hipMemcpyHostToDevice));
+        k_fill_q<<<(unsigned)((Dp * Dp + 255) / 256), 256, 0, st>>>(f->Qfull, f->Kg, f->iwp, f->n, dp);
+    }
+    const bool fresh = (f->Sqinv == nullptr);
+    if (fresh) HIPCHK(ctx, hipMalloc(&f->Sqinv, sizeof(double) * (size_t)mp * mp));
+    HIPCHK(ctx, hipMemsetAsync(f->flags, 0, sizeof(int) * (f->RT + f->CB + 1), st));
+    HIPCHK(ctx, hipMemsetAsync(f->info_err, 0x7f, sizeof(int), st));
+    MeasModel mm{f->ell_col, f->ell_val, f->ellw, f->d, f->m, f->dp, f->mp,
+                 nordsieck_scale(f->nu, 0, dt), nordsieck_scale(f->nu, 1, dt)};
+    switch (f->n) {
+        case 2: run_error_model_sweep<2>(f, mm); break;
+        case 3: run_error_model_sweep<3>(f, mm); break;
+        case 4: run_error_model_sweep<4>(f, mm); break;
+        default: return -1;
+    }
+    // Sq^-1 = Lq^-T Lq^-1 = T T^T with T = rows of the identity block after the sweep
+    const double* T = f->F + ((long)mp + Dp + NB) * mp;
+    k_ttt<<<dim3(mp / 16, mp / 16), 256, 0, st>>>(T, f->Sqinv, mp);
+    std::vector<double> hd((size_t)m);
+    int inf = 0;
+    HIPCHK(ctx, hipMemcpy2DAsync(hd.data(), sizeof(double), f->G, sizeof(double) * (mp + 1), sizeof(double), m,
+                                 hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(&inf, f->info_err, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        ctx->err = std::string("prepare_error_model: ") + hipGetErrorString(e);
+        return -2;
+    }
+    if (inf < mp) {
+        ctx->err = inf == -2 ? "prepare_error_model: a dependency wait timed out"
+                             : "prepare_error_model: Sq not positive definite at pivot " + std::to_string(inf);
+        return inf == -2 ? -2 : -3;
+    }
+    f->sqdiag = hd;
+    f->sq_dt = dt;
+    if (fresh) drop_graphs(f);
     return 0;
 }
 

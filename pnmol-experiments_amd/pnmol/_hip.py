@@ -71,6 +71,7 @@ SYMBOLS = {
     "pnmol_filter_steps_end": (ctypes.c_int, [_vp, _vp, _c_double_p, _c_double_p, ctypes.POINTER(StepOut)]),
     "pnmol_filter_prepare_steps": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_double]),
     "pnmol_filter_last_steps_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
+    "pnmol_filter_prepare_error_model": (ctypes.c_int, [_vp, ctypes.c_double]),
     "pnmol_filter_debug_read": (ctypes.c_int, [_vp, ctypes.c_int, _c_double_p, ctypes.c_long]),
     "pnmol_filter_dims": (ctypes.c_int, [_vp] + [ctypes.POINTER(ctypes.c_int)] * 5),
 }
@@ -170,6 +171,11 @@ class Filter:
         v = [ctypes.c_int(0) for _ in range(5)]
         self.lib.pnmol_filter_dims(self.handle, *[ctypes.byref(x) for x in v])
         return dict(zip(("d", "n", "m", "dp", "mp"), (x.value for x in v)))
+
+    def prepare_error_model(self, dt):
+        """Step-invariant part of `estimate_error` for step size dt, computed on the device from the current operator."""
+        self.ctx.check(self.lib.pnmol_filter_prepare_error_model(self.handle, float(dt)), "pnmol_filter_prepare_error_model")
+        self.error_model_dt = float(dt)
 
     def set_error_model(self, dt, Sq_inv, Sq_diag):
         a, b = _f64(Sq_inv, (self.m, self.m)), _f64(Sq_diag, (self.m,))

@@ -135,9 +135,14 @@ class _WhiteNoiseEK1Base(pdefilter.PDEFilter):
             self._error_models = {key: model}
         return self._error_models[key]
 
+    error_model_on_host = False   # True: Sq^-1 from the host (`_error_model`, an O(m^3) solve per new dt) instead of the GPU
+
     def _ensure_error_model(self, pde, dt):
         if self._device_filter.error_model_dt != float(dt):
-            self._device_filter.set_error_model(dt, *self._error_model(pde, dt))
+            if self.error_model_on_host:
+                self._device_filter.set_error_model(dt, *self._error_model(pde, dt))
+            else:
+                self._device_filter.prepare_error_model(dt)   # Sq factorised by the step's own kernels
 
     # ------------------------------------------------------------------ hot path
     def _device_state_of(self, state, pde):
@@ -163,7 +168,10 @@ class _WhiteNoiseEK1Base(pdefilter.PDEFilter):
             m_at = flt.predict_mean(dev_in, dt)
             M, shift = self._linearize(pde, m_at, state.t + dt)
             flt.set_operator(M, shift)
-            flt.set_error_model(dt, *self._error_model(pde, dt, M=M))
+            if self.error_model_on_host:
+                flt.set_error_model(dt, *self._error_model(pde, dt, M=M))
+            else:
+                flt.prepare_error_model(dt)
         else:
             self._ensure_error_model(pde, dt)
         dev_out, info, error = self._device_filter.step(dev_in, dt)

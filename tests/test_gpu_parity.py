@@ -256,3 +256,20 @@ def test_concurrent_problems_on_one_gpu():
         assert all(o.info == -1 for o in infos)
         assert np.array_equal(m, m_seq) and np.array_equal(s, s_seq)
         assert [o.diffusion_squared_local for o in infos] == [o.diffusion_squared_local for o in i_seq]
+
+
+@pytest.mark.parametrize("N,bcond", [(40, "dirichlet"), (96, "neumann")])
+def test_device_error_model_matches_host(hip_ctx, N, bcond):
+    """`pnmol_filter_prepare_error_model` (Sq factorised on the GPU by the step's own kernels) against the host
+    O(m^3) solve of `_error_model` and against the oracle's `estimate_error` (white.py:153-162)."""
+    dt = 2.0 ** -6
+    pde, solver, opde, osolver = make_pair(N, 2, dt, 3, bcond=bcond)
+    s0 = solver.initialize(pde)
+    a, _ = solver.attempt_step(s0, dt, pde)                      # device error model (default)
+    solver.error_model_on_host = True
+    solver._device_filter.error_model_dt = None
+    b, _ = solver.attempt_step(s0, dt, pde)
+    np.testing.assert_allclose(a.error_estimate, b.error_estimate, rtol=1e-8)
+    o0 = osolver.initialize(opde)
+    oa, _ = osolver.attempt_step(o0, dt, opde)
+    np.testing.assert_allclose(a.error_estimate, oa.error_estimate, rtol=1e-5, atol=1e-9 * np.abs(oa.error_estimate).max())
