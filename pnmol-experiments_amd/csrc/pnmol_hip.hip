@@ -897,6 +897,65 @@ __device__ __forceinline__ void vecops_rows4(const VecArgs& va, const double* __
     }
 }
 
+// This wave's share of  sum_{k0 <= k < k1} A_k B_k^T  (32x32 tiles; A_k at Abase + k NB, B_k at Bbase + k NB, both
+// already offset to this lane's row and column slice): tiles k0 + w, k0 + w + 4, ...  The full 32x32 partial sum goes
+// to `sp` (C layout, row stride TLD).  Loads are unconditional (clamped index) and ping-pong between two register
+// sets, so the wait counts are static and the loads of the next tile stay in flight behind the 32 MFMAs of this one.
+__device__ __forceinline__ void ksplit_partial(double* sp, const double* __restrict__ Abase, const double* __restrict__ Bbase,
+                                               int k0, int k1, long ld, int w, int l) {
+    const int fr = l & 15, fk = l >> 4;
+    d4 p00 = {0, 0, 0, 0}, p01 = p00, p10 = p00, p11 = p00;
+    FragTile a0, b0, a1, b1;
+    auto mfma32 = [&](const FragTile& a, const FragTile& b) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            p00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.lo.v[s], b.lo.v[s], p00, 0, 0, 0);
+            p01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.lo.v[s], b.hi.v[s], p01, 0, 0, 0);
+            p10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.hi.v[s], b.lo.v[s], p10, 0, 0, 0);
+            p11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.hi.v[s], b.hi.v[s], p11, 0, 0, 0);
+        }
+    };
+    const int nk = (k0 + w < k1) ? (k1 - k0 - w + 3) >> 2 : 0;  // my tiles: k_t = k0 + w + 4 t, t < nk
+    if (nk > 0) {
+        tile_ld(a0, Abase + (long)(k0 + w) * NB, ld);
+        tile_ld(b0, Bbase + (long)(k0 + w) * NB, ld);
+    }
+    int t = 0;
+    for (; t + 2 <= nk; t += 2) {
+        const long ka = k0 + w + 4 * (t + 1), kb = k0 + w + 4 * (t + 2 < nk ? t + 2 : nk - 1);
+        tile_ld(a1, Abase + ka * NB, ld);
+        tile_ld(b1, Bbase + ka * NB, ld);
+        mfma32(a0, b0);
+        tile_ld(a0, Abase + kb * NB, ld);
+        tile_ld(b0, Bbase + kb * NB, ld);
+        mfma32(a1, b1);
+    }
+    if (t < nk) mfma32(a0, b0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        sp[(fk + 4 * r) * TLD + fr] = p00[r];
+        sp[(fk + 4 * r) * TLD + 16 + fr] = p01[r];
+        sp[(16 + fk + 4 * r) * TLD + fr] = p10[r];
+        sp[(16 + fk + 4 * r) * TLD + 16 + fr] = p11[r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Helpers.  A row of S with a large index H falls behind the chain near the end: the one-step-ahead partial sum of its
+// target step t runs over t-1 tile pairs (0.5 us each), more than a panel period allows.  Its OLD part (tiles
+// k < kh = t-1-KMAX, published long ago) is therefore done by the workgroup of row CB-1-H, which finished its own
+// row early (dependencies keep pointing to lower block indices).  Nobody ever blocks on an unscheduled helper: a target
+// is claimed (CAS on claim[H][t]: 0 free, 1 helper computing, 2 helper done, 3 owner took it) by the helper only once
+// its inputs are there, and an owner that finds it unclaimed simply does the old part itself.
+// ------------------------------------------------------------------------------------------
+constexpr int HELP_KMAX = 8;
+__device__ __forceinline__ int helper_share(int H, int t, int CB) {
+    const int h = CB - 1 - H;
+    if (h >= H - 1 || t < h + 3) return 0;  // no helper for this row / helper not free that early
+    const int kh = t - 1 - HELP_KMAX;
+    return kh > 0 ? kh : 0;
+}
+
 // Arguments of the covariance down-date role (workgroups RT .. RT + pairs - 1 of a fused launch)
 struct DowndateArgs {
     const double* Ppred;  // P-  (Dp x Dp)
@@ -1034,10 +1093,10 @@ __device__ __forceinline__ void sweep_downdate_role(SweepLds& L, const DowndateA
     SWEEP_STAMP(5);
 }
 
-template <int N, bool FUSED>
+template <int N, bool FUSED, bool CHAINHELP = FUSED>
 __global__ __launch_bounds__(256) void k_sweep(const double* __restrict__ G, double* F, double* Linv, int ld, int CB,
                                                int RT, int* flags, int* info_base, const int* __restrict__ ctr,
-                                               DowndateArgs dd) {
+                                               DowndateArgs dd, int* claim, double* hs_scratch) {
     __shared__ __attribute__((aligned(16))) SweepLds L;
     const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);  // w: wave-uniform (SGPR)
     const int wr = w >> 1, wc = w & 1, fr = l & 15, fk = l >> 4;
@@ -1108,6 +1167,38 @@ __global__ __launch_bounds__(256) void k_sweep(const double* __restrict__ G, dou
                 acc[r] -= (L.sP[0][offC + 4 * r * TLD] + L.sP[1][offC + 4 * r * TLD]) +
                           (L.sP[2][offC + 4 * r * TLD] + L.sP[3][offC + 4 * r * TLD]);
         }
+        if (CHAINHELP && chain) {
+            const int kh = helper_share(I, j, CB);
+            if (kh > 0) {  // the old part of this step's sum: from the helper, or done here if it never got to it
+                int* cl = claim + (long)I * CB + j;
+                __syncthreads();
+                if (tid == 0) {
+                    int c = atomicCAS(cl, 0, 3);
+                    for (int spins = 0; c == 1 && !L.dead; ++spins) {
+                        c = flag_ld(cl);
+                        if (spins > SWEEP_SPIN_LIMIT || flag_ld(fabort)) {
+                            L.dead = 1;
+                            flag_st(fabort, 1);
+                        }
+                    }
+                    L.seen[0] = c;
+                }
+                __syncthreads();
+                const int c = L.seen[0];
+                if (c == 2) {
+                    const double* hs = hs_scratch + ((long)I * CB + j) * NB * NB;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] -= hs[(wr * 16 + fk + 4 * r) * NB + colC];
+                } else if (c == 0) {
+                    ksplit_partial(L.sP[w], Xown, F + ((long)j * NB + fr) * ld + 8 * fk, 0, kh, ld, w, l);
+                    __syncthreads();
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[r] -= (L.sP[0][offC + 4 * r * TLD] + L.sP[1][offC + 4 * r * TLD]) +
+                                  (L.sP[2][offC + 4 * r * TLD] + L.sP[3][offC + 4 * r * TLD]);
+                }
+            }
+        }
         if (j >= 1) {  // newest tile L_{j,j-1}; X_{j-1} is still in LDS
             sweep_wait(&L, frow, fdiag, fabort, j, jn_ok, j, 0, false, sn, tid);
             SWEEP_TRACE(j, 1);
@@ -1131,44 +1222,8 @@ __global__ __launch_bounds__(256) void k_sweep(const double* __restrict__ G, dou
             if (j >= 1) {
                 sweep_wait(&L, frow, fdiag, fabort, j, jn_ok, 0, j, false, sn, tid);
                 SWEEP_TRACE(j, 3);
-                d4 p00 = {0, 0, 0, 0}, p01 = p00, p10 = p00, p11 = p00;
-                const double* Lnext = F + ((long)(j + 1) * NB + fr) * ld + 8 * fk;
-                FragTile a0, b0, a1, b1;  // ping-pong: no register copies, so the loads of tile k+4 stay in flight
-                auto mfma32 = [&](const FragTile& a, const FragTile& b) {
-#pragma unroll
-                    for (int s = 0; s < 8; ++s) {
-                        p00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.lo.v[s], b.lo.v[s], p00, 0, 0, 0);
-                        p01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.lo.v[s], b.hi.v[s], p01, 0, 0, 0);
-                        p10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.hi.v[s], b.lo.v[s], p10, 0, 0, 0);
-                        p11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.hi.v[s], b.hi.v[s], p11, 0, 0, 0);
-                    }
-                };
-                // my tiles: k_t = w + 4 t, t < nk.  Loads are unconditional (clamped index) so that the wait counts are
-                // static and the loads of the next tile stay in flight behind the 32 MFMAs of the current one.
-                const int nk = (w < j) ? (j - w + 3) >> 2 : 0;
-                if (nk > 0) {
-                    tile_ld(a0, Xown + (long)w * NB, ld);
-                    tile_ld(b0, Lnext + (long)w * NB, ld);
-                }
-                int t = 0;
-                for (; t + 2 <= nk; t += 2) {
-                    const long k1 = w + 4 * (t + 1), k2 = w + 4 * (t + 2 < nk ? t + 2 : nk - 1);
-                    tile_ld(a1, Xown + k1 * NB, ld);
-                    tile_ld(b1, Lnext + k1 * NB, ld);
-                    mfma32(a0, b0);
-                    tile_ld(a0, Xown + k2 * NB, ld);
-                    tile_ld(b0, Lnext + k2 * NB, ld);
-                    mfma32(a1, b1);
-                }
-                if (t < nk) mfma32(a0, b0);
-                double* sp = L.sP[w];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    sp[(fk + 4 * r) * TLD + fr] = p00[r];
-                    sp[(fk + 4 * r) * TLD + 16 + fr] = p01[r];
-                    sp[(16 + fk + 4 * r) * TLD + fr] = p10[r];
-                    sp[(16 + fk + 4 * r) * TLD + 16 + fr] = p11[r];
-                }
+                const int kh = CHAINHELP && chain ? helper_share(I, j + 1, CB) : 0;  // tiles [0, kh): a helper's
+                ksplit_partial(L.sP[w], Xown, F + ((long)(j + 1) * NB + fr) * ld + 8 * fk, kh, j, ld, w, l);
             }
         }
         if (j + 1 == nsteps) SWEEP_STAMP(1);
@@ -1240,6 +1295,50 @@ __global__ __launch_bounds__(256) void k_sweep(const double* __restrict__ G, dou
         __hip_atomic_store(&L.pub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     if (tid == 0 && L.dead) atomicMin(info, -2);
+    if constexpr (CHAINHELP) {
+        // this row is done: help row H = CB-1-I with the old part of its partial sums (see helper_share)
+        const int H = CB - 1 - I;
+        if (I < H - 1) {
+            const double* Xh = F + ((long)H * NB + fr) * ld + 8 * fk;
+            for (int t = I + 3; t < H; ++t) {
+                const int kh = helper_share(H, t, CB);
+                if (kh <= 0) continue;
+                int* cl = claim + (long)H * CB + t;
+                __syncthreads();
+                if (tid == 0) {
+                    int got = 0;  // 1: claimed, 0: the owner was faster, -1: inputs never came, stop helping
+                    for (int spins = 0;; ++spins) {
+                        if (flag_ld(cl) != 0) break;
+                        if (flag_ld(frow + H) >= kh && flag_ld(frow + t) >= kh) {
+                            got = atomicCAS(cl, 0, 1) == 0;
+                            break;
+                        }
+                        if (spins > 4096 || flag_ld(fabort)) {
+                            got = -1;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                    L.seen[0] = got;
+                }
+                __syncthreads();
+                const int got = L.seen[0];
+                if (got < 0) break;
+                if (got == 0) continue;
+                ksplit_partial(L.sP[w], Xh, F + ((long)t * NB + fr) * ld + 8 * fk, 0, kh, ld, w, l);
+                __syncthreads();
+                double* hs = hs_scratch + ((long)H * CB + t) * NB * NB;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    wt_st(&hs[(wr * 16 + fk + 4 * r) * NB + colC],
+                          (L.sP[0][offC + 4 * r * TLD] + L.sP[1][offC + 4 * r * TLD]) +
+                              (L.sP[2][offC + 4 * r * TLD] + L.sP[3][offC + 4 * r * TLD]));
+                drain_vmem();
+                __syncthreads();
+                if (tid == 0) flag_st(cl, 2);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1505,7 +1604,8 @@ struct pnmol_ctx {
 struct pnmol_filter {
     pnmol_ctx* ctx = nullptr;
     int d = 0, n = 0, nu = 0, nB = 0, m = 0, dp = 0, mp = 0, CB = 0, RBS = 0, RBW = 0, RT = 0, ellw = 0;
-    int* flags = nullptr;  // k_sweep dependency flags: row[RT], diag[CB], abort
+    int* flags = nullptr;  // k_sweep dependency flags: row[RT], diag[CB], abort, claim[CB*CB] (helpers)
+    double* hs_scratch = nullptr;  // helpers' partial sums, one tile per (row, target step)
     int sweep_mode = 2;    // PNMOL_HIP_SWEEP: 2 = k_sweep with the covariance down-date riding along in the same launch,
                            // 1 = k_sweep, then k_downdate; 0 = k_diag0 + one k_panel launch per panel, then k_downdate
     int ds = 0;  // spatial components of the state (= d, or 2d for the latent-force model [u; eps])
@@ -1578,7 +1678,7 @@ int launch_step(pnmol_filter* f, const double* Pin, const double* min, double fr
 
     // K1: P- = A P A^T + Q  (+ one workgroup: m-, z, step counter)
     k_predict<N><<<dim3(dp / 32, dp / 8 + 1), dim3(32, 8), sizeof(double) * Dp, st>>>(
-        Pin, f->Ppred, f->Kg, c, dp, min, f->mpred, f->shift, f->G, f->zbuf, mm, f->ctr, f->flags, f->RT + f->CB + 1);
+        Pin, f->Ppred, f->Kg, c, dp, min, f->mpred, f->shift, f->G, f->zbuf, mm, f->ctr, f->flags, f->RT + f->CB + 1 + f->CB * f->CB);
     // K2: G = [S; P-H^T; z; I] and the first diagonal block
     k_front<<<dim3((mp + 255) / 256, (unsigned)(Dp + 2 * mp)), 256, 0, st>>>(f->Ppred, f->G, f->rdiag, f->Rdense, mm, Dp);
     const long rowI0 = (long)mp + Dp + NB;
@@ -1593,11 +1693,13 @@ int launch_step(pnmol_filter* f, const double* Pin, const double* min, double fr
         const int t32 = dp / NB, pairs = t32 * (t32 + 1) / 2;
         dd.vrows = (int)((Dp + mp + pairs - 1) / pairs);  // the vector ops ride at the end of the down-date workgroups
         if constexpr (N <= 3)
-            k_sweep<N, true><<<f->RT + pairs, 256, 0, st>>>(f->G, f->F, f->Linv, mp, f->CB, f->RT, f->flags, f->info, f->ctr, dd);
+            k_sweep<N, true><<<f->RT + pairs, 256, 0, st>>>(f->G, f->F, f->Linv, mp, f->CB, f->RT, f->flags, f->info, f->ctr, dd,
+                                                            f->flags + f->RT + f->CB + 1, f->hs_scratch);
     } else {
         if (f->sweep_mode == 1) {
             // K3': the sweep alone as one dataflow launch
-            k_sweep<N, false><<<f->RT, 256, 0, st>>>(f->G, f->F, f->Linv, mp, f->CB, f->RT, f->flags, f->info, f->ctr, dd);
+            k_sweep<N, false><<<f->RT, 256, 0, st>>>(f->G, f->F, f->Linv, mp, f->CB, f->RT, f->flags, f->info, f->ctr, dd,
+                                                     f->flags + f->RT + f->CB + 1, f->hs_scratch);
         } else {
             k_diag0<<<1, 128, 0, st>>>(f->G, f->F, f->Linv, mp, f->info, f->sdiag, f->ctr);
             // K3: right-looking sweep, one launch per 32-column panel
@@ -1754,7 +1856,8 @@ int run_error_model_sweep(pnmol_filter* f, const MeasModel& mm) {
     const long Dp = f->Dp;
     k_front<<<dim3((mp + 255) / 256, (unsigned)(Dp + 2 * mp)), 256, 0, st>>>(f->Qfull, f->G, f->rdiag, f->Rdense, mm, Dp);
     DowndateArgs dd{};
-    k_sweep<N, false><<<f->RT, 256, 0, st>>>(f->G, f->F, f->Linv, mp, f->CB, f->RT, f->flags, f->info_err, f->one, dd);
+    k_sweep<N, false><<<f->RT, 256, 0, st>>>(f->G, f->F, f->Linv, mp, f->CB, f->RT, f->flags, f->info_err, f->one, dd,
+                                             f->flags + f->RT + f->CB + 1, f->hs_scratch);
     return 0;
 }
 
@@ -1920,8 +2023,9 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
     FCHK(hipMalloc(&f->ctr, sizeof(int)));
     if (const char* gc = std::getenv("PNMOL_HIP_GRAPH_CHUNK")) f->graph_chunk = std::atoi(gc) / 2 * 2;
     FCHK(hipMalloc(&f->sdiag, sizeof(double) * (mp + 1)));
-    FCHK(hipMalloc(&f->flags, sizeof(int) * (f->RT + f->CB + 1)));
-    FCHK(hipMemset(f->flags, 0, sizeof(int) * (f->RT + f->CB + 1)));
+    FCHK(hipMalloc(&f->flags, sizeof(int) * (f->RT + f->CB + 1 + f->CB * f->CB)));
+    FCHK(hipMemset(f->flags, 0, sizeof(int) * (f->RT + f->CB + 1 + f->CB * f->CB)));
+    FCHK(hipMalloc(&f->hs_scratch, sizeof(double) * (size_t)f->CB * f->CB * NB * NB));
     if (const char* e = std::getenv("PNMOL_HIP_SWEEP")) f->sweep_mode = std::atoi(e);
     if (f->sweep_mode == 2 && n > 3) f->sweep_mode = 1;  // the fused down-date role is built for n <= 3
     FCHK(hipMemcpy(f->ell_col, ecol.data(), sizeof(int) * ecol.size(), hipMemcpyHostToDevice));
@@ -1954,7 +2058,7 @@ int pnmol_filter_destroy(pnmol_filter* f) {
     if (f->h_pin) hipHostFree(f->h_pin);
     void* ptrs[] = {f->ell_col, f->ell_val, f->Kg,   f->rdiag,   f->Rdense, f->shift,     f->G,        f->F,
                     f->Linv,    f->Ppred,   f->mpred, f->zbuf,   f->var,    f->Sqinv,     f->rec,      f->part,  f->sdiag,
-                    f->info,    f->tmpP,    f->tmpMean, f->rec_means, f->rec_stds, f->flags, f->Qfull, f->one, f->info_err};
+                    f->info,    f->tmpP,    f->tmpMean, f->rec_means, f->rec_stds, f->flags, f->Qfull, f->one, f->info_err, f->hs_scratch};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (f->ev0) hipEventDestroy(f->ev0);
