@@ -204,24 +204,12 @@ __device__ __forceinline__ double s_entry_w(const double* __restrict__ Ppred, lo
 }
 
 // ------------------------------------------------------------------------------------------
-// 32x32 Cholesky + triangular inverse by ONE wave, all data in registers.
-// Lane i < 32 holds row i of the symmetric tile in v[0..31]; lane 32+c starts from e_c.  Column step j:
-// every lane scales v[j] by 1/sqrt(pivot) and subtracts v[j] * l_kj from v[k], k > j, with l_kj
-// broadcast from lane k (v_readlane).  On lanes 0..31 that is right-looking Cholesky (v[k] = L[i][k]);
-// on lanes 32..63 the same instruction stream applies the elementary inverses E_j^-1 to the identity, so
-// lane 32+c ends with column c of L^-1 (v[r] = Linv[r][c]).  No LDS, no barriers.
+// Helpers of the 32x32 diagonal-block factorisation
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ double bcast_lane(double x, int src) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
     return __hiloint2double(hi, lo);
-}
-
-// 1/sqrt(p): hardware seed + one cubically convergent step  y <- y + y e (1/2 + 3/8 e),  e = 1 - p y^2
-__device__ __forceinline__ double rsqrt_nr(double p) {
-    const double y = __builtin_amdgcn_rsq(p);
-    const double e = fma(-(p * y), y, 1.0);
-    return fma(y * e, fma(0.375, e, 0.5), y);
 }
 
 //
@@ -232,80 +220,6 @@ __device__ __forceinline__ double rsqrt_nr(double p) {
 // a tiny positive number and an equally negligible update).  Only a pivot that is negative at the 1e-3 level
 // of a significant row (or NaN) is reported through `info` (checked for all 32 pivots at once after the loop).
 //
-// The stream is issue-bound (one wave, ~5 cycles per instruction), so it is kept lean: broadcasts are
-// software-pipelined in groups of four (no SGPR-hazard nops), the column step is branch-free (uniform
-// branches let LLVM sink earlier columns' updates to their first use, which serialises them and spills SGPRs)
-// and every column's updates are pinned by empty-asm register barriers.
-// Column step J.  The scaled column is written to LDS once; the first FAST updates (the ones the next pivot
-// depends on) use v_readlane broadcasts, the bulk reads its multipliers back from LDS two at a time
-// (same-address ds_read_b128 = broadcast), which halves the instruction count of the issue-bound stream.
-template <int J>
-__device__ __forceinline__ void potrf32_col(double (&v)[NB], int lane, double thr, double& pv, double* colbuf) {
-    constexpr int FAST = 3;
-    const double p = bcast_lane(v[J], J);
-    const bool ok = p > bcast_lane(thr, J);
-    pv = (lane == J) ? p : pv;
-#if defined(PNMOL_ABL) && PNMOL_ABL == 2
-    const double rsq = 0.5;
-#else
-    const double rsq = rsqrt_nr(ok ? p : 1.0);
-#endif
-    const double vj = ok ? v[J] * rsq : 0.0;
-    v[J] = vj;
-    const double nvj = -vj;
-    constexpr int KS = J + 1 + FAST;             // first column of the bulk
-    constexpr int KA = (KS + 1) & ~1;            // first even (16-byte aligned) bulk column
-    double* cb = colbuf + (J & 1) * 64;          // ping-pong: older reads of the other buffer may be in flight
-    if constexpr (KS < NB) cb[lane] = vj;        // lanes 32..63 land in the unused upper half
-    double2 bb[(NB - KA) / 2 > 0 ? (NB - KA) / 2 : 1];
-    double bodd = 0.0;
-    if constexpr (KS < NB) {
-        if constexpr (KS < KA) bodd = cb[KS];
-#pragma unroll
-        for (int q = 0; q < (NB - KA) / 2; ++q) bb[q] = *reinterpret_cast<const double2*>(cb + KA + 2 * q);
-    }
-#pragma unroll
-    for (int k = J + 1; k < NB && k < KS; ++k) v[k] = fma(nvj, bcast_lane(vj, k), v[k]);
-#if defined(PNMOL_ABL) && PNMOL_ABL == 1
-    if constexpr (false) {
-#else
-    if constexpr (KS < NB) {
-#endif
-        if constexpr (KS < KA) v[KS] = fma(nvj, bodd, v[KS]);
-#pragma unroll
-        for (int q = 0; q < (NB - KA) / 2; ++q) {
-            v[KA + 2 * q] = fma(nvj, bb[q].x, v[KA + 2 * q]);
-            v[KA + 2 * q + 1] = fma(nvj, bb[q].y, v[KA + 2 * q + 1]);
-        }
-    }
-    // Register barriers (no instructions): the fast updates are complete here; the bulk may still be scheduled
-    // into the next column's pivot-chain latency, but no further (it is pinned at the end of the next column).
-#pragma unroll
-    for (int k = J + 1; k < NB && k < KS; ++k) asm volatile("" : "+v"(v[k]));
-    if constexpr (J > 0) {
-#pragma unroll
-        for (int k = J + FAST; k < NB; ++k) asm volatile("" : "+v"(v[k]));
-    }
-}
-
-template <int... Js>
-__device__ __forceinline__ void potrf32_cols(double (&v)[NB], int lane, double thr, double& pv, double* colbuf,
-                                             std::integer_sequence<int, Js...>) {
-    (potrf32_col<Js>(v, lane, thr, pv, colbuf), ...);
-}
-
-__device__ __forceinline__ void potrf32_inv_wave(double (&v)[NB], int lane, int* info, int base,
-                                                 double sdv /* lane q<32: |S_qq| of this block */, double smax,
-                                                 double* colbuf /* LDS, 128 doubles, 16-byte aligned */) {
-    const double thr = 1e-13 * sdv;
-    double pv = 1.0;  // lane j (< 32) records pivot j
-    potrf32_cols(v, lane, thr, pv, colbuf, std::make_integer_sequence<int, NB>{});
-    if (lane < NB) {
-        const bool fatal = !(pv > thr) && (!(pv == pv) || (pv < -1e-3 * sdv && sdv > 1e-12 * smax));
-        const unsigned long long m = __ballot(fatal);
-        if (m != 0 && lane == 0) atomicMin(info, base + __builtin_ctzll(m));
-    }
-}
 
 // ------------------------------------------------------------------------------------------
 // Two-wave variant of the 32x32 Cholesky + inverse (the one the step uses).
@@ -485,29 +399,6 @@ __device__ __forceinline__ void diag2w_from_lds(const double* T, double* __restr
             if constexpr (WT) __hip_atomic_store(&Li[(2 * q + h) * NB + i], u[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else Li[(2 * q + h) * NB + i] = u[q];
         }
-    }
-}
-
-// wave 0 of a workgroup factorises the LDS tile T (row stride TLD) and writes L (upper zeroed) to
-// Fd (leading dim ld) and L^-1 to Li (32x32 row-major)
-__device__ __forceinline__ void diag_from_lds(const double* T, double* __restrict__ Fd, long ld,
-                                              double* __restrict__ Li, int lane, int* info, int base,
-                                              const double* __restrict__ sdiag, double smax, double* colbuf) {
-    double v[NB];
-    const int q = lane & 31;
-    const double sdv = fabs(sdiag[base + q]);
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        const double t = T[q * TLD + k];
-        v[k] = (lane < 32) ? t : (k == q ? 1.0 : 0.0);
-    }
-    potrf32_inv_wave(v, lane, info, base, sdv, smax, colbuf);
-    if (lane < 32) {
-#pragma unroll
-        for (int k = 0; k < NB; ++k) Fd[(long)q * ld + k] = (k <= q) ? v[k] : 0.0;
-    } else {
-#pragma unroll
-        for (int r = 0; r < NB; ++r) Li[r * NB + q] = v[r];
     }
 }
 

@@ -4,26 +4,6 @@
 
 #include <random>
 
-__global__ __launch_bounds__(64) void k_time_diag(const double* __restrict__ G, double* __restrict__ F,
-                                                  double* __restrict__ Linv, int* info, double* sdiag,
-                                                  unsigned long long* out) {
-    __shared__ double sT[NB * TLD];
-    __shared__ __attribute__((aligned(16))) double colbuf[128];
-    const int lane = threadIdx.x;
-    for (int e = lane; e < NB * NB; e += 64) sT[(e >> 5) * TLD + (e & 31)] = G[(e >> 5) * NB + (e & 31)];
-    __syncthreads();
-    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    diag_from_lds(sT, F, NB, Linv, lane, info, 0, sdiag, sdiag[NB], colbuf);
-    __builtin_amdgcn_s_waitcnt(0);
-    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
-    if (lane == 0) {
-        out[0] = t1 - t0;
-        out[1] = r1 - r0;
-    }
-}
-
 __global__ __launch_bounds__(128) void k_time_diag2w(const double* __restrict__ G, double* __restrict__ F,
                                                      double* __restrict__ Linv, int* info, double* sdiag,
                                                      unsigned long long* out) {
@@ -100,13 +80,6 @@ int main() {
                 e2 = std::max(e2, std::fabs(t - (i == j)));
             }
         std::printf("2-wave: max |LL^T - S| = %.3e   max |Linv L - I| = %.3e\n", e1, e2);
-    }
-    for (int rep = 0; rep < 3; ++rep) {
-        k_time_diag<<<1, 64>>>(dG, dF, dL, dinfo, dsd, dout);
-        hipDeviceSynchronize();
-        hipMemcpy(out, dout, 16, hipMemcpyDeviceToHost);
-        std::printf("rep %d: %llu cycles, %.2f us (realtime), clock %.2f GHz\n", rep, out[0], out[1] / 100.0,
-                    out[0] / (out[1] / 100.0) / 1e3);
     }
     std::vector<double> L(NB * NB), X(NB * NB);
     hipMemcpy(L.data(), dF, sizeof(double) * NB * NB, hipMemcpyDeviceToHost);
