@@ -100,6 +100,49 @@ __device__ __forceinline__ double h_row_dot_w(const HRow& r, const double* __res
     return v;
 }
 
+// The vector part of the predict (one workgroup of 256 threads): m- = A m, z = H m- + shift (into the z row of G and
+// zbuf), reset of the dependency flags of the coming k_sweep.  `mpl` = Dp doubles of LDS.
+struct RoleArgs {
+    IwpConsts c;
+    int dp;
+    const double* min;
+    double* mpred;
+    const double* shift;
+    double* G;
+    double* zbuf;
+    MeasModel mm;
+    int* flags;
+    int nflags;
+};
+
+template <int N>
+__device__ __forceinline__ void predict_vectors(double* mpl, int tid, const IwpConsts& c, int dp, const double* __restrict__ min,
+                                                double* __restrict__ mpred, const double* __restrict__ shift,
+                                                double* __restrict__ G, double* __restrict__ zbuf, const MeasModel& mm,
+                                                int* __restrict__ flags, int nflags) {
+    const long Dp = (long)N * dp;
+    for (int e = tid; e < nflags; e += 256) flags[e] = 0;  // dependency flags of this step's k_sweep
+    for (int j = tid; j < dp; j += 256) {
+        double x[N];
+#pragma unroll
+        for (int a = 0; a < N; ++a) x[a] = c.ts[a] * min[a * dp + j];
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int q = 0; q < N; ++q) sacc += c.A1[a * MAXN + q] * x[q];
+            mpl[a * dp + j] = sacc;
+            mpred[a * dp + j] = sacc;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < mm.mp; i += 256) {
+        const double v = (i < mm.m) ? h_row_dot(mm, i, mpl) + shift[i] : 0.0;
+        G[((long)mm.mp + Dp) * mm.mp + i] = v;
+        zbuf[i] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // K1  predict:  P-_ab = sum_ce A1[a,c] A1[b,e] ts_c ts_e P_ce + Q1[a,b] K      (HBM-bound pass)
 // One extra workgroup (blockIdx.y == 0) does the vector work of the step start: m- = A m, z = H m- + shift
@@ -118,26 +161,7 @@ __global__ __launch_bounds__(256) void k_predict(const double* __restrict__ Pin,
         if (blockIdx.x != 0) return;
         extern __shared__ double mpl[];  // predicted mean, Dp doubles
         const int tid = threadIdx.y * 32 + threadIdx.x;
-        for (int e = tid; e < nflags; e += 256) flags[e] = 0;  // dependency flags of this step's k_sweep
-        for (int j = tid; j < dp; j += 256) {
-            double x[N];
-#pragma unroll
-            for (int a = 0; a < N; ++a) x[a] = c.ts[a] * min[a * dp + j];
-#pragma unroll
-            for (int a = 0; a < N; ++a) {
-                double sacc = 0.0;
-#pragma unroll
-                for (int q = 0; q < N; ++q) sacc += c.A1[a * MAXN + q] * x[q];
-                mpl[a * dp + j] = sacc;
-                mpred[a * dp + j] = sacc;
-            }
-        }
-        __syncthreads();
-        for (int i = tid; i < mm.mp; i += 256) {
-            const double v = (i < mm.m) ? h_row_dot(mm, i, mpl) + shift[i] : 0.0;
-            G[((long)mm.mp + Dp) * mm.mp + i] = v;
-            zbuf[i] = v;
-        }
+        predict_vectors<N>(mpl, tid, c, dp, min, mpred, shift, G, zbuf, mm, flags, nflags);
         if (tid == 0) *ctr += 1;
         return;
     }
@@ -855,6 +879,13 @@ struct DowndateArgs {
     int dp;               // padded points per derivative (multiple of 32)
     int vrows;            // rows of the vector ops (vecops_rows) each down-date workgroup does at its end
     VecArgs va;
+    // constant-step loop: the epilogue also predicts the NEXT step's covariance, P-' = A P A^T + Q, in place of P-
+    // (a lane holds all n x n derivative entries of its point pairs), so the loop's steps need no k_predict pass over
+    // P; P itself is then only written by the step whose counter equals *last_ctr.
+    double* Pnext;        // = Ppred (in place: a workgroup only reads its own tile of P-, at its start) or nullptr
+    const double* Kg;     // K = Gamma Gamma^T (dp x dp)
+    const int* last_ctr;  // step counter value of the last step of the call
+    double A1[MAXN * MAXN], Q1[MAXN * MAXN];
 };
 
 // Down-date role: one workgroup per lower pair (J >= K) of 32-point tiles, all N x N derivative blocks.  Wave
@@ -864,7 +895,7 @@ struct DowndateArgs {
 template <int N>
 __device__ __forceinline__ void sweep_downdate_role(SweepLds& L, const DowndateArgs& dd, const double* F, int ld, int CB,
                                                     int RBS, const int* frow, int* fabort, int* info, int pair, int tid,
-                                                    int l, int w) {
+                                                    int l, int w, int slot) {
     const int fr = l & 15, fk = l >> 4, qr = w >> 1, qc = w & 1;
     const int T32 = dd.dp / NB;
     int J = (int)((sqrt(8.0 * pair + 1.0) - 1.0) * 0.5);  // pair = J (J + 1) / 2 + K
@@ -932,28 +963,61 @@ __device__ __forceinline__ void sweep_downdate_role(SweepLds& L, const DowndateA
                     acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-fa[a].v[s], fb[b].v[s], acc[a][b], 0, 0, 0);
     }
     // epilogue: the tile, diag(P), and (J != K) the mirror image, transposed through wave-private LDS so that it
-    // leaves as 128-byte rows
+    // leaves as 128-byte rows; in the constant-step loop also (or, except for the last step, instead) the next
+    // step's predicted covariance
     double* stg = L.sP[w];
+    const bool write_p = dd.Pnext == nullptr || (slot + 1 == *dd.last_ctr);
+    auto put_block = [&](double* dst, const d4& v, long row0, long col0) {
 #pragma unroll
-    for (int a = 0; a < N; ++a)
-#pragma unroll
-        for (int b = 0; b < N; ++b) {
-            const long row0 = (long)a * dd.dp + J * NB + qr * 16, col0 = (long)b * dd.dp + K * NB + qc * 16;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double v = acc[a][b][r];
-                dd.Pout[(row0 + fk + 4 * r) * Dp + col0 + fr] = v;
-                if (J == K && a == b && qr == qc && fk + 4 * r == fr) dd.var[row0 + fr] = v;
-                if (J != K) stg[(fk + 4 * r) * 17 + fr] = v;
-            }
-            if (J != K) {
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int r = 0; r < 4; ++r)  // stg[i][c] = tile(i, c); mirror row c (= fk + 4 r) holds tile(:, c)
-                    dd.Pout[(col0 + fk + 4 * r) * Dp + row0 + fr] = stg[fr * 17 + fk + 4 * r];
-                __builtin_amdgcn_wave_barrier();
-            }
+        for (int r = 0; r < 4; ++r) {
+            dst[(row0 + fk + 4 * r) * Dp + col0 + fr] = v[r];
+            if (J != K) stg[(fk + 4 * r) * 17 + fr] = v[r];
         }
+        if (J != K) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 4; ++r)  // stg[i][c] = tile(i, c); mirror row c (= fk + 4 r) holds tile(:, c)
+                dst[(col0 + fk + 4 * r) * Dp + row0 + fr] = stg[fr * 17 + fk + 4 * r];
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+#pragma unroll
+    for (int a = 0; a < N; ++a) {
+        const long row0 = (long)a * dd.dp + J * NB + qr * 16;
+        if (J == K && qr == qc) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (fk + 4 * r == fr) dd.var[row0 + fr] = acc[a][a][r];
+        }
+        if (write_p) {
+#pragma unroll
+            for (int b = 0; b < N; ++b) put_block(dd.Pout, acc[a][b], row0, (long)b * dd.dp + K * NB + qc * 16);
+        }
+    }
+    if (dd.Pnext) {  // P-' = A1 X A1^T + Q1 K[j,k] per point pair, X = the n x n entries this lane holds
+        d4 kjk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) kjk[r] = dd.Kg[(long)(J * NB + qr * 16 + fk + 4 * r) * dd.dp + K * NB + qc * 16 + fr];
+        d4 T[N][N];
+#pragma unroll
+        for (int a = 0; a < N; ++a)
+#pragma unroll
+            for (int e = 0; e < N; ++e) {
+                d4 t = {0, 0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < N; ++q) t += dd.A1[a * MAXN + q] * acc[q][e];
+                T[a][e] = t;
+            }
+#pragma unroll
+        for (int a = 0; a < N; ++a)
+#pragma unroll
+            for (int b = 0; b < N; ++b) {
+                d4 pn = dd.Q1[a * MAXN + b] * kjk;
+#pragma unroll
+                for (int e = 0; e < N; ++e) pn += T[a][e] * dd.A1[b * MAXN + e];
+                put_block(dd.Pnext, pn, (long)a * dd.dp + J * NB + qr * 16, (long)b * dd.dp + K * NB + qc * 16);
+            }
+    }
     // The vector ops of the step ride at the end of this role (rows [pair * vrows, +vrows) of vecops_rows): by now the
     // whole sweep is finished or about to be; a row still waits for the row block it reads and for the r^T block.
     {
@@ -1005,7 +1069,7 @@ __global__ __launch_bounds__(256) void k_sweep(const double* __restrict__ G, dou
             }
             __syncthreads();
             SWEEP_STAMP(0);
-            sweep_downdate_role<N>(L, dd, F, ld, CB, CB, frow, fabort, info, I - RT, tid, l, w);
+            sweep_downdate_role<N>(L, dd, F, ld, CB, CB, frow, fabort, info, I - RT, tid, l, w, *ctr - 1);
             return;
         }
     }
@@ -1434,12 +1498,34 @@ __global__ __launch_bounds__(256) void k_ttt(const double* __restrict__ T, doubl
 
 // per-step read-out of the parity quantities (experiments/figure1.py:76-80), raw coordinates;
 // block 0 also reduces the partial sums of the vector-op rows into rec[0..2] (fixed order: deterministic)
+template <int N, bool ROLE>
 __global__ __launch_bounds__(256) void k_readout(const double* __restrict__ mean, const double* __restrict__ var,
                                                  double* __restrict__ means_base, double* __restrict__ stds_base,
                                                  double s0, int d, const double* __restrict__ part,
-                                                 double* __restrict__ rec_base, int mp, const int* __restrict__ ctr) {
+                                                 double* __restrict__ rec_base, int mp, int* __restrict__ ctr,
+                                                 RoleArgs ra, int* __restrict__ tickets) {
+    const int slot = __builtin_amdgcn_readfirstlane(*ctr) - 1;  // (the load has completed before the ticket below)
+    if constexpr (ROLE) {
+        // Constant-step loop: the last block prepares the NEXT step (the vector part of its predict, whose covariance
+        // part the down-date epilogue has already done) beside this step's read-out blocks.  It moves the step counter
+        // only after every read-out block has taken its slot (ticket counter; those blocks have lower indices).
+        if (blockIdx.x == gridDim.x - 1) {
+            extern __shared__ double mpl[];
+            predict_vectors<N>(mpl, threadIdx.x, ra.c, ra.dp, ra.min, ra.mpred, ra.shift, ra.G, ra.zbuf, ra.mm, ra.flags,
+                               ra.nflags);
+            if (threadIdx.x == 0) {
+                int spins = 0;
+                while (__hip_atomic_load(tickets, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x - 1 &&
+                       ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+                *ctr = slot + 2;
+                __hip_atomic_store(tickets, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+        __syncthreads();  // (slot read by all threads of this block)
+        if (threadIdx.x == 0) atomicAdd(tickets, 1);
+    }
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int slot = *ctr - 1;
     double* means = means_base ? means_base + (size_t)slot * d : nullptr;
     double* stds = stds_base ? stds_base + (size_t)slot * d : nullptr;
     double* rec = rec_base + 4 * (size_t)slot;
@@ -1495,6 +1581,9 @@ struct pnmol_ctx {
 struct pnmol_filter {
     pnmol_ctx* ctx = nullptr;
     int d = 0, n = 0, nu = 0, nB = 0, m = 0, dp = 0, mp = 0, CB = 0, RBS = 0, RBW = 0, RT = 0, ellw = 0;
+    int* tickets = nullptr;   // device: read-out blocks that have taken their slot (k_readout with the next step's role)
+    int* last_ctr = nullptr;  // device: step-counter value of the last step of the running pnmol_filter_steps call
+    int fuse_predict = 1;     // PNMOL_HIP_FUSE_PREDICT: predict the next step's covariance in the down-date epilogue
     int* flags = nullptr;  // k_sweep dependency flags: row[RT], diag[CB], abort, claim[CB*CB] (helpers)
     double* hs_scratch = nullptr;  // helpers' partial sums, one tile per (row, target step)
     int sweep_mode = 2;    // PNMOL_HIP_SWEEP: 2 = k_sweep with the covariance down-date riding along in the same launch,
@@ -1531,6 +1620,7 @@ struct pnmol_filter {
         double dt;
         int nsteps;
         bool have_sq;
+        bool fused;
         hipGraphExec_t exec;
         bool launched;  // the first launch of an executable graph costs ~50 ms of host time (ROCm 7.2)
     };
@@ -1552,9 +1642,16 @@ namespace {
 
 void drop_graphs(pnmol_filter* f);
 
+// kind of a step inside the launch sequence: FULL = self-contained (predict, ..., P written); in the constant-step loop
+// of pnmol_filter_steps the down-date epilogue already predicts the next step's covariance (fused_loop()), so FIRST does
+// the full predict and STEADY steps only run k_predict's vector workgroup; both write P only in the call's last step.
+enum StepKind { STEP_FULL = 0, STEP_FIRST = 1, STEP_STEADY = 2 };
+
+inline bool fused_loop(const pnmol_filter* f) { return f->sweep_mode == 2 && f->n <= 3 && f->fuse_predict != 0; }
+
 template <int N>
 int launch_step(pnmol_filter* f, const double* Pin, const double* min, double frame_dt, double dt, double* Pout,
-                double* mout, double* varout, bool record) {
+                double* mout, double* varout, bool record, StepKind kind) {
     pnmol_ctx* ctx = f->ctx;
     hipStream_t st = ctx->stream;
     IwpConsts c = f->iwp;
@@ -1568,7 +1665,10 @@ int launch_step(pnmol_filter* f, const double* Pin, const double* min, double fr
     const long Dp = f->Dp;
 
     // K1: P- = A P A^T + Q  (+ one workgroup: m-, z, step counter)
-    k_predict<N><<<dim3(dp / 32, dp / 8 + 1), dim3(32, 8), sizeof(double) * Dp, st>>>(
+    // (STEADY steps of the constant-step loop need none of it: the previous step's down-date epilogue made P- and its
+    //  k_readout launch did the vector part)
+    if (kind != STEP_STEADY)
+        k_predict<N><<<dim3(dp / 32, dp / 8 + 1), dim3(32, 8), sizeof(double) * Dp, st>>>(
         Pin, f->Ppred, f->Kg, c, dp, min, f->mpred, f->shift, f->G, f->zbuf, mm, f->ctr, f->flags, f->RT + f->CB + 1 + f->CB * f->CB);
     // K2: G = [S; P-H^T; z; I] and the first diagonal block
     k_front<<<dim3((mp + 255) / 256, (unsigned)(Dp + 2 * mp)), 256, 0, st>>>(f->Ppred, f->G, f->rdiag, f->Rdense, mm, Dp);
@@ -1577,7 +1677,9 @@ int launch_step(pnmol_filter* f, const double* Pin, const double* min, double fr
     const bool have_sq = (f->Sqinv != nullptr && f->sq_dt == dt);
     VecArgs va{f->mpred, f->F + ((long)mp + Dp) * mp, f->F + rowI0 * mp, f->zbuf, have_sq ? f->Sqinv : nullptr,
                mout, f->part};
-    DowndateArgs dd{f->Ppred, Pout, varout, dp, 0, va};
+    DowndateArgs dd{f->Ppred, Pout, varout, dp, 0, va, kind == STEP_FULL ? nullptr : f->Ppred, f->Kg, f->last_ctr, {}, {}};
+    std::memcpy(dd.A1, f->iwp.A1, sizeof(dd.A1));
+    std::memcpy(dd.Q1, f->iwp.Q1, sizeof(dd.Q1));
     if (f->sweep_mode == 2) {
         // K3'+K4: the whole sweep as one dataflow launch (one workgroup per 32-row block) with the covariance
         // down-date riding along (one workgroup per pair of 32-point tiles), then the vector ops
@@ -1606,9 +1708,18 @@ int launch_step(pnmol_filter* f, const double* Pin, const double* min, double fr
         k_downdate<N><<<dim3(tiles, tiles + vrows), 256, 0, st>>>(f->Ppred, W, Pout, varout, dp, mp, 0, mp / 8, va);
     }
     // K5: read-out + deterministic reduction of the per-row partial sums
-    k_readout<<<(f->d + 255) / 256, 256, 0, st>>>(mout, varout, record ? f->rec_means : nullptr,
-                                                  record ? f->rec_stds : nullptr, nordsieck_scale(f->nu, 0, dt), f->d,
-                                                  f->part, f->rec, mp, f->ctr);
+    IwpConsts cn = f->iwp;  // the next step of the loop has the same dt: no frame change
+    for (int a = 0; a < MAXN; ++a) cn.ts[a] = 1.0;
+    RoleArgs ra{cn, dp, mout, f->mpred, f->shift, f->G, f->zbuf, mm, f->flags, f->RT + f->CB + 1 + f->CB * f->CB};
+    const unsigned rblocks = (f->d + 255) / 256;
+    if (kind == STEP_FULL)
+        k_readout<N, false><<<rblocks, 256, 0, st>>>(mout, varout, record ? f->rec_means : nullptr,
+                                                    record ? f->rec_stds : nullptr, nordsieck_scale(f->nu, 0, dt), f->d,
+                                                    f->part, f->rec, mp, f->ctr, ra, f->tickets);
+    else
+        k_readout<N, true><<<rblocks + 1, 256, sizeof(double) * Dp, st>>>(
+            mout, varout, record ? f->rec_means : nullptr, record ? f->rec_stds : nullptr, nordsieck_scale(f->nu, 0, dt),
+            f->d, f->part, f->rec, mp, f->ctr, ra, f->tickets);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         ctx->err = std::string("kernel launch: ") + hipGetErrorString(e);
@@ -1618,11 +1729,11 @@ int launch_step(pnmol_filter* f, const double* Pin, const double* min, double fr
 }
 
 int dispatch_step(pnmol_filter* f, const double* Pin, const double* min, double frame_dt, double dt, double* Pout,
-                  double* mout, double* varout, bool record) {
+                  double* mout, double* varout, bool record, StepKind kind = STEP_FULL) {
     switch (f->n) {
-        case 2: return launch_step<2>(f, Pin, min, frame_dt, dt, Pout, mout, varout, record);
-        case 3: return launch_step<3>(f, Pin, min, frame_dt, dt, Pout, mout, varout, record);
-        case 4: return launch_step<4>(f, Pin, min, frame_dt, dt, Pout, mout, varout, record);
+        case 2: return launch_step<2>(f, Pin, min, frame_dt, dt, Pout, mout, varout, record, kind);
+        case 3: return launch_step<3>(f, Pin, min, frame_dt, dt, Pout, mout, varout, record, kind);
+        case 4: return launch_step<4>(f, Pin, min, frame_dt, dt, Pout, mout, varout, record, kind);
     }
     return -1;
 }
@@ -1641,7 +1752,8 @@ int get_graph(pnmol_filter* f, double* P0, double* M0, double* P1, double* M1, d
     pnmol_ctx* ctx = f->ctx;
     const bool have_sq = (f->Sqinv != nullptr && f->sq_dt == dt);
     for (auto& g : f->graphs)
-        if (g.P0 == P0 && g.P1 == P1 && g.var == var && g.dt == dt && g.nsteps == nsteps && g.have_sq == have_sq) {
+        if (g.P0 == P0 && g.P1 == P1 && g.var == var && g.dt == dt && g.nsteps == nsteps && g.have_sq == have_sq &&
+            g.fused == fused_loop(f)) {
             *out = g.exec;
             return 0;
         }
@@ -1650,8 +1762,8 @@ int get_graph(pnmol_filter* f, double* P0, double* M0, double* P1, double* M1, d
     HIPCHK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
     int rc = 0;
     for (int it = 0; it < nsteps && rc == 0; ++it)
-        rc = (it & 1) ? dispatch_step(f, P1, M1, dt, dt, P0, M0, var, true)
-                      : dispatch_step(f, P0, M0, dt, dt, P1, M1, var, true);
+        rc = (it & 1) ? dispatch_step(f, P1, M1, dt, dt, P0, M0, var, true, fused_loop(f) ? STEP_STEADY : STEP_FULL)
+                      : dispatch_step(f, P0, M0, dt, dt, P1, M1, var, true, fused_loop(f) ? STEP_STEADY : STEP_FULL);
     hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
     if (rc != 0 || e != hipSuccess) {
         if (graph) (void)hipGraphDestroy(graph);
@@ -1665,7 +1777,7 @@ int get_graph(pnmol_filter* f, double* P0, double* M0, double* P1, double* M1, d
         ctx->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e);
         return -2;
     }
-    f->graphs.push_back({P0, P1, var, dt, nsteps, have_sq, exec, false});
+    f->graphs.push_back({P0, P1, var, dt, nsteps, have_sq, fused_loop(f), exec, false});
     *out = exec;
     return 0;
 }
@@ -1702,7 +1814,8 @@ int prepare_graphs(pnmol_filter* f, pnmol_state* s, int k, double dt, hipGraphEx
     *gbig = *gpair = nullptr;
     if (f->graph_chunk < 2) return 0;
     double *curP = s->P, *curM = s->mean, *nxtP = f->tmpP, *nxtM = f->tmpMean;
-    const int lead = (s->frame_dt != dt) ? 1 : 0;  // a frame change has its own constants: that step runs eagerly
+    // a frame change has its own constants, and in the fused loop the first step does the full predict: that step runs eagerly
+    const int lead = (s->frame_dt != dt || fused_loop(f)) ? 1 : 0;
     const int rest = k - lead;
     double *gP0 = lead ? nxtP : curP, *gM0 = lead ? nxtM : curM, *gP1 = lead ? curP : nxtP, *gM1 = lead ? curM : nxtM;
     int rc = 0;
@@ -1918,6 +2031,11 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
     FCHK(hipMemset(f->flags, 0, sizeof(int) * (f->RT + f->CB + 1 + f->CB * f->CB)));
     FCHK(hipMalloc(&f->hs_scratch, sizeof(double) * (size_t)f->CB * f->CB * NB * NB));
     if (const char* e = std::getenv("PNMOL_HIP_SWEEP")) f->sweep_mode = std::atoi(e);
+    if (const char* e = std::getenv("PNMOL_HIP_FUSE_PREDICT")) f->fuse_predict = std::atoi(e);
+    FCHK(hipMalloc(&f->last_ctr, sizeof(int)));
+    FCHK(hipMemset(f->last_ctr, 0, sizeof(int)));
+    FCHK(hipMalloc(&f->tickets, sizeof(int)));
+    FCHK(hipMemset(f->tickets, 0, sizeof(int)));
     if (f->sweep_mode == 2 && n > 3) f->sweep_mode = 1;  // the fused down-date role is built for n <= 3
     FCHK(hipMemcpy(f->ell_col, ecol.data(), sizeof(int) * ecol.size(), hipMemcpyHostToDevice));
     FCHK(hipMemcpy(f->ell_val, eval.data(), sizeof(double) * eval.size(), hipMemcpyHostToDevice));
@@ -1949,7 +2067,7 @@ int pnmol_filter_destroy(pnmol_filter* f) {
     if (f->h_pin) hipHostFree(f->h_pin);
     void* ptrs[] = {f->ell_col, f->ell_val, f->Kg,   f->rdiag,   f->Rdense, f->shift,     f->G,        f->F,
                     f->Linv,    f->Ppred,   f->mpred, f->zbuf,   f->var,    f->Sqinv,     f->rec,      f->part,  f->sdiag,
-                    f->info,    f->tmpP,    f->tmpMean, f->rec_means, f->rec_stds, f->flags, f->Qfull, f->one, f->info_err, f->hs_scratch};
+                    f->info,    f->tmpP,    f->tmpMean, f->rec_means, f->rec_stds, f->flags, f->Qfull, f->one, f->info_err, f->hs_scratch, f->last_ctr, f->tickets};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (f->ev0) hipEventDestroy(f->ev0);
@@ -2270,6 +2388,8 @@ int pnmol_filter_steps_begin(pnmol_filter* f, pnmol_state* s, int k, double dt) 
     hipStream_t st = ctx->stream;
     HIPCHK(ctx, hipMemsetAsync(f->info, 0x7f, sizeof(int) * k, st));
     HIPCHK(ctx, hipMemsetAsync(f->ctr, 0, sizeof(int), st));
+    HIPCHK(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(f->last_ctr), k, 1, st));
+    const bool fused = fused_loop(f);
     double *curP = s->P, *curM = s->mean, *nxtP = f->tmpP, *nxtM = f->tmpMean;
     double frame = s->frame_dt;
     const bool trace = std::getenv("PNMOL_HIP_TRACE") != nullptr;
@@ -2283,19 +2403,21 @@ int pnmol_filter_steps_begin(pnmol_filter* f, pnmol_state* s, int k, double dt) 
     int it = 0;
     while (it < k) {
         const int left = k - it;
-        if (frame == dt && gbig && left >= f->graph_chunk) {
+        const bool may_graph = frame == dt && (it > 0 || !fused);  // fused loop: step 0 does the full predict (eager)
+        if (may_graph && gbig && left >= f->graph_chunk) {
             HIPCHK(ctx, hipGraphLaunch(gbig, st));
             for (auto& g : f->graphs) g.launched = g.launched || g.exec == gbig;
             it += f->graph_chunk;  // even number of steps: buffers are back where they started
             continue;
         }
-        if (frame == dt && gpair && left >= 2) {
+        if (may_graph && gpair && left >= 2) {
             HIPCHK(ctx, hipGraphLaunch(gpair, st));
             for (auto& g : f->graphs) g.launched = g.launched || g.exec == gpair;
             it += 2;
             continue;
         }
-        rc = dispatch_step(f, curP, curM, frame, dt, nxtP, nxtM, s->var, true);
+        rc = dispatch_step(f, curP, curM, frame, dt, nxtP, nxtM, s->var, true,
+                           !fused ? STEP_FULL : (it == 0 ? STEP_FIRST : STEP_STEADY));
         if (rc != 0) return rc;
         double* t;
         t = curP, curP = nxtP, nxtP = t;
