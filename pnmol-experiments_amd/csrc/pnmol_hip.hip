@@ -440,12 +440,11 @@ __device__ __forceinline__ void tile_g2s(const double* __restrict__ g, long ld, 
 //   [Dp, Dp+mp)         row of S = H P- H^T + R             (straight from P-, see s_entry)
 //   [Dp+mp, Dp+2mp)     row of the trailing identity block  (the sweep turns it into Ls^-T)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_front(const double* __restrict__ Ppred, double* __restrict__ G,
-                                               const double* __restrict__ rdiag, const double* __restrict__ Rdense,
-                                               MeasModel mm, long Dp) {
+__device__ __forceinline__ void front_block(const double* __restrict__ Ppred, double* __restrict__ G,
+                                            const double* __restrict__ rdiag, const double* __restrict__ Rdense,
+                                            const MeasModel& mm, long Dp, int bx, long y) {
     const int tid = threadIdx.x;
-    const int i = blockIdx.x * 256 + tid;
-    const long y = blockIdx.y;
+    const int i = bx * 256 + tid;
     const int mp = mm.mp;
     const bool narrow = mm.w <= HW;
     if (y < Dp) {
@@ -482,6 +481,12 @@ __global__ __launch_bounds__(256) void k_front(const double* __restrict__ Ppred,
     }
     const long q = y - Dp - mp;
     if (i < mp) G[((long)mp + Dp + NB + q) * mp + i] = (q == i) ? 1.0 : 0.0;
+}
+
+__global__ __launch_bounds__(256) void k_front(const double* __restrict__ Ppred, double* __restrict__ G,
+                                               const double* __restrict__ rdiag, const double* __restrict__ Rdense,
+                                               MeasModel mm, long Dp) {
+    front_block(Ppred, G, rdiag, Rdense, mm, Dp, blockIdx.x, blockIdx.y);
 }
 
 // first diagonal block: diag(S) -> sdiag, its max -> sdiag[mp]; F[0,0] = chol(G[0,0]), Linv[0] = its inverse
@@ -1503,19 +1508,30 @@ __global__ __launch_bounds__(256) void k_readout(const double* __restrict__ mean
                                                  double* __restrict__ means_base, double* __restrict__ stds_base,
                                                  double s0, int d, const double* __restrict__ part,
                                                  double* __restrict__ rec_base, int mp, int* __restrict__ ctr,
-                                                 RoleArgs ra, int* __restrict__ tickets) {
+                                                 RoleArgs ra, int* __restrict__ tickets, int rblocks,
+                                                 const double* __restrict__ Ppred, const double* __restrict__ rdiag,
+                                                 const double* __restrict__ Rdense) {
+    if constexpr (ROLE) {
+        // blocks behind the read-out and role blocks: the NEXT step's k_front (G from the P- the down-date epilogue
+        // has just written) -- independent of the rest of this launch, which hides behind it
+        if ((int)blockIdx.x > rblocks) {
+            const int fb = blockIdx.x - rblocks - 1, gx = (mp + 255) / 256;
+            front_block(Ppred, ra.G, rdiag, Rdense, ra.mm, (long)N * ra.dp, fb % gx, fb / gx);
+            return;
+        }
+    }
     const int slot = __builtin_amdgcn_readfirstlane(*ctr) - 1;  // (the load has completed before the ticket below)
     if constexpr (ROLE) {
         // Constant-step loop: the last block prepares the NEXT step (the vector part of its predict, whose covariance
         // part the down-date epilogue has already done) beside this step's read-out blocks.  It moves the step counter
         // only after every read-out block has taken its slot (ticket counter; those blocks have lower indices).
-        if (blockIdx.x == gridDim.x - 1) {
+        if ((int)blockIdx.x == rblocks) {
             extern __shared__ double mpl[];
             predict_vectors<N>(mpl, threadIdx.x, ra.c, ra.dp, ra.min, ra.mpred, ra.shift, ra.G, ra.zbuf, ra.mm, ra.flags,
                                ra.nflags);
             if (threadIdx.x == 0) {
                 int spins = 0;
-                while (__hip_atomic_load(tickets, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x - 1 &&
+                while (__hip_atomic_load(tickets, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < rblocks &&
                        ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(1);
                 *ctr = slot + 2;
                 __hip_atomic_store(tickets, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1608,6 +1624,7 @@ struct pnmol_filter {
     double *tmpP = nullptr, *tmpMean = nullptr;
     double *rec_means = nullptr, *rec_stds = nullptr;
     double* h_pin = nullptr;  // pinned host staging: [rec 4k | means k*d | stds k*d | info k ints]
+    double* h_pin_dev = nullptr;  // the same buffer as the device sees it (mapped)
     int rec_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.f;
@@ -1670,8 +1687,9 @@ int launch_step(pnmol_filter* f, const double* Pin, const double* min, double fr
     if (kind != STEP_STEADY)
         k_predict<N><<<dim3(dp / 32, dp / 8 + 1), dim3(32, 8), sizeof(double) * Dp, st>>>(
         Pin, f->Ppred, f->Kg, c, dp, min, f->mpred, f->shift, f->G, f->zbuf, mm, f->ctr, f->flags, f->RT + f->CB + 1 + f->CB * f->CB);
-    // K2: G = [S; P-H^T; z; I] and the first diagonal block
-    k_front<<<dim3((mp + 255) / 256, (unsigned)(Dp + 2 * mp)), 256, 0, st>>>(f->Ppred, f->G, f->rdiag, f->Rdense, mm, Dp);
+    // K2: G = [S; P-H^T; z; I]  (STEADY: done by the previous step's k_readout launch)
+    if (kind != STEP_STEADY)
+        k_front<<<dim3((mp + 255) / 256, (unsigned)(Dp + 2 * mp)), 256, 0, st>>>(f->Ppred, f->G, f->rdiag, f->Rdense, mm, Dp);
     const long rowI0 = (long)mp + Dp + NB;
     const double* W = f->F + (long)mp * mp;
     const bool have_sq = (f->Sqinv != nullptr && f->sq_dt == dt);
@@ -1715,11 +1733,12 @@ int launch_step(pnmol_filter* f, const double* Pin, const double* min, double fr
     if (kind == STEP_FULL)
         k_readout<N, false><<<rblocks, 256, 0, st>>>(mout, varout, record ? f->rec_means : nullptr,
                                                     record ? f->rec_stds : nullptr, nordsieck_scale(f->nu, 0, dt), f->d,
-                                                    f->part, f->rec, mp, f->ctr, ra, f->tickets);
-    else
-        k_readout<N, true><<<rblocks + 1, 256, sizeof(double) * Dp, st>>>(
+                                                    f->part, f->rec, mp, f->ctr, ra, f->tickets, (int)rblocks, f->Ppred, f->rdiag,
+                                                    f->Rdense);
+    else  // + the next step's vector predict (1 block) and k_front ((mp/256 rounded up) x (Dp + 2 mp) blocks)
+        k_readout<N, true><<<rblocks + 1 + (unsigned)(((mp + 255) / 256) * (Dp + 2 * mp)), 256, sizeof(double) * Dp, st>>>(
             mout, varout, record ? f->rec_means : nullptr, record ? f->rec_stds : nullptr, nordsieck_scale(f->nu, 0, dt),
-            f->d, f->part, f->rec, mp, f->ctr, ra, f->tickets);
+            f->d, f->part, f->rec, mp, f->ctr, ra, f->tickets, (int)rblocks, f->Ppred, f->rdiag, f->Rdense);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         ctx->err = std::string("kernel launch: ") + hipGetErrorString(e);
@@ -1824,6 +1843,36 @@ int prepare_graphs(pnmol_filter* f, pnmol_state* s, int k, double dt, hipGraphEx
     return rc;
 }
 
+// Per-call results go to the host through a KERNEL that writes the mapped pinned staging buffer, not through
+// hipMemcpyAsync: on this pool device-to-host SDMA copies of a few hundred KB sporadically stall the stream for ~70 ms
+// (1 run in 5 at N <= 256; never with HSA_ENABLE_SDMA=0).
+__global__ __launch_bounds__(256) void k_copy_out(const double* __restrict__ rec, const double* __restrict__ means,
+                                                  const double* __restrict__ stds, const int* __restrict__ info,
+                                                  double* __restrict__ out, int k, int d, int cap) {
+    const long nm = (long)k * d;
+    double* hm = out + (size_t)4 * cap;
+    double* hs = hm + (size_t)cap * d;
+    int* hi = reinterpret_cast<int*>(hs + (size_t)cap * d);
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nm; e += (long)gridDim.x * 256) {
+        if (means) hm[e] = means[e];
+        if (stds) hs[e] = stds[e];
+    }
+    if (blockIdx.x == 0) {
+        for (int e = threadIdx.x; e < 4 * k; e += 256) out[e] = rec[e];
+        for (int e = threadIdx.x; e < k; e += 256) hi[e] = info[e];
+    }
+}
+
+// start of a pnmol_filter_step(s) call: info words to "no failure", step counter to 0, last step's counter value
+// (a kernel rather than three runtime memsets, see k_copy_out)
+__global__ void k_init_call(int* __restrict__ info, int k, int* __restrict__ ctr, int* __restrict__ last_ctr) {
+    for (int e = threadIdx.x; e < k; e += blockDim.x) info[e] = 0x7f7f7f7f;
+    if (threadIdx.x == 0) {
+        *ctr = 0;
+        *last_ctr = k;
+    }
+}
+
 int ensure_rec(pnmol_filter* f, int k) {
     if (k <= f->rec_cap) return 0;
     if (k < 128) k = 128;
@@ -1836,7 +1885,8 @@ int ensure_rec(pnmol_filter* f, int k) {
     if (f->h_pin) hipHostFree(f->h_pin);
     f->rec = nullptr, f->info = nullptr, f->rec_means = nullptr, f->rec_stds = nullptr, f->h_pin = nullptr;
     f->rec_cap = 0;
-    HIPCHK(ctx, hipHostMalloc(&f->h_pin, sizeof(double) * ((size_t)4 * k + 2 * (size_t)k * f->d + (size_t)k), 0));
+    HIPCHK(ctx, hipHostMalloc(&f->h_pin, sizeof(double) * ((size_t)4 * k + 2 * (size_t)k * f->d + (size_t)k), hipHostMallocMapped));
+    HIPCHK(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&f->h_pin_dev), f->h_pin, 0));
     HIPCHK(ctx, hipMalloc(&f->rec, sizeof(double) * 4 * k));
     HIPCHK(ctx, hipMalloc(&f->info, sizeof(int) * k));
     HIPCHK(ctx, hipMalloc(&f->rec_means, sizeof(double) * (size_t)k * f->d));
@@ -2345,15 +2395,14 @@ int pnmol_filter_step(pnmol_filter* f, const pnmol_state* in, double dt, pnmol_s
     }
     pnmol_ctx* ctx = f->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipMemsetAsync(f->info, 0x7f, sizeof(int), ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(f->ctr, 0, sizeof(int), ctx->stream));
+    k_init_call<<<1, 64, 0, ctx->stream>>>(f->info, 1, f->ctr, f->last_ctr);
     int rc = dispatch_step(f, in->P, in->mean, in->frame_dt, dt, out->P, out->mean, out->var, false);
     if (rc != 0) return rc;
-    double rec[4];
-    int inf = 0;
-    HIPCHK(ctx, hipMemcpyAsync(rec, f->rec, sizeof(rec), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(&inf, f->info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    k_copy_out<<<1, 256, 0, ctx->stream>>>(f->rec, nullptr, nullptr, f->info, f->h_pin_dev, 1, f->d, f->rec_cap);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    double rec[4];
+    std::memcpy(rec, f->h_pin, sizeof(rec));
+    const int inf = *reinterpret_cast<const int*>(f->h_pin + (size_t)4 * f->rec_cap + 2 * (size_t)f->rec_cap * f->d);
     out->t = in->t + dt;
     out->frame_dt = dt;
     const bool have_sq = (f->Sqinv != nullptr && f->sq_dt == dt);
@@ -2386,9 +2435,7 @@ int pnmol_filter_steps_begin(pnmol_filter* f, pnmol_state* s, int k, double dt) 
     int rc = ensure_rec(f, k);
     if (rc != 0) return rc;
     hipStream_t st = ctx->stream;
-    HIPCHK(ctx, hipMemsetAsync(f->info, 0x7f, sizeof(int) * k, st));
-    HIPCHK(ctx, hipMemsetAsync(f->ctr, 0, sizeof(int), st));
-    HIPCHK(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(f->last_ctr), k, 1, st));
+    k_init_call<<<1, 256, 0, st>>>(f->info, k, f->ctr, f->last_ctr);
     const bool fused = fused_loop(f);
     double *curP = s->P, *curM = s->mean, *nxtP = f->tmpP, *nxtM = f->tmpMean;
     double frame = s->frame_dt;
@@ -2433,15 +2480,7 @@ int pnmol_filter_steps_begin(pnmol_filter* f, pnmol_state* s, int k, double dt) 
         s->P = curP, s->mean = curM;
     }
     // device -> pinned staging (allocated in ensure_rec); handed to the caller by pnmol_filter_steps_end
-    HIPCHK(ctx, hipMemcpyAsync(f->h_pin, f->rec, sizeof(double) * 4 * k, hipMemcpyDeviceToHost, st));
-    {
-        double* hm = f->h_pin + (size_t)4 * f->rec_cap;
-        double* hs = hm + (size_t)f->rec_cap * f->d;
-        int* inf = reinterpret_cast<int*>(hs + (size_t)f->rec_cap * f->d);
-        HIPCHK(ctx, hipMemcpyAsync(inf, f->info, sizeof(int) * k, hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipMemcpyAsync(hm, f->rec_means, sizeof(double) * (size_t)k * f->d, hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipMemcpyAsync(hs, f->rec_stds, sizeof(double) * (size_t)k * f->d, hipMemcpyDeviceToHost, st));
-    }
+    k_copy_out<<<64, 256, 0, st>>>(f->rec, f->rec_means, f->rec_stds, f->info, f->h_pin_dev, k, f->d, f->rec_cap);
     if (trace)
         std::fprintf(stderr, "[pnmol] steps_begin(k=%d): prepare %.2f ms, enqueue %.2f ms, graphs big=%d pair=%d\n", k, tB - tA,
                      tC - tB, gbig != nullptr, gpair != nullptr);
