@@ -22,8 +22,6 @@ import time
 ROOT = pathlib.Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT / "pnmol-experiments_amd"))
 
-os.environ.setdefault("HSA_ENABLE_SDMA", "0")   # before torch / HIP start: see pnmol/_hip.py
-
 import numpy as np  # noqa: E402
 
 PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X fp64 matrix peak (vendor figure)

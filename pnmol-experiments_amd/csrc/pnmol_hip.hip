@@ -1843,9 +1843,8 @@ int prepare_graphs(pnmol_filter* f, pnmol_state* s, int k, double dt, hipGraphEx
     return rc;
 }
 
-// Per-call results go to the host through a KERNEL that writes the mapped pinned staging buffer, not through
-// hipMemcpyAsync: on this pool device-to-host SDMA copies of a few hundred KB sporadically stall the stream for ~70 ms
-// (1 run in 5 at N <= 256; never with HSA_ENABLE_SDMA=0).
+// Per-call results go to the host through a KERNEL that writes the mapped pinned staging buffer: one launch instead
+// of four hipMemcpyAsync calls (no SDMA queue, no runtime copy path inside the step loop).
 __global__ __launch_bounds__(256) void k_copy_out(const double* __restrict__ rec, const double* __restrict__ means,
                                                   const double* __restrict__ stds, const int* __restrict__ info,
                                                   double* __restrict__ out, int k, int d, int cap) {
@@ -1864,7 +1863,7 @@ __global__ __launch_bounds__(256) void k_copy_out(const double* __restrict__ rec
 }
 
 // start of a pnmol_filter_step(s) call: info words to "no failure", step counter to 0, last step's counter value
-// (a kernel rather than three runtime memsets, see k_copy_out)
+// (a kernel rather than three runtime memsets)
 __global__ void k_init_call(int* __restrict__ info, int k, int* __restrict__ ctr, int* __restrict__ last_ctr) {
     for (int e = threadIdx.x; e < k; e += blockDim.x) info[e] = 0x7f7f7f7f;
     if (threadIdx.x == 0) {

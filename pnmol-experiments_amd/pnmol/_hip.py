@@ -9,11 +9,6 @@ import pathlib
 
 import numpy as np
 
-# Host<->device copies through blit kernels instead of the SDMA engines: with SDMA queues alive in the process the
-# compute queue of a short step loop is sporadically rescheduled ~80 ms late on this platform (1 run in 6 at N <= 256,
-# none in 40 with this setting; measured with bench.py).  Must be in the environment before the HIP runtime starts;
-# set HSA_ENABLE_SDMA yourself to override.
-os.environ.setdefault("HSA_ENABLE_SDMA", "0")
 
 _c_double_p = ctypes.POINTER(ctypes.c_double)
 _HERE = pathlib.Path(__file__).resolve().parent
