@@ -273,3 +273,40 @@ def test_device_error_model_matches_host(hip_ctx, N, bcond):
     o0 = osolver.initialize(opde)
     oa, _ = osolver.attempt_step(o0, dt, opde)
     np.testing.assert_allclose(a.error_estimate, oa.error_estimate, rtol=1e-5, atol=1e-9 * np.abs(oa.error_estimate).max())
+
+
+@pytest.mark.parametrize("N,splits", [(40, (1, 2, 5)), (96, (3, 4, 1, 1, 6))])
+def test_loop_steps_match_single_steps(hip_ctx, N, splits):
+    """Inside `pnmol_filter_steps` the step boundary is moved (2 launches per step: the down-date epilogue predicts the
+    next covariance in place, the posterior covariance is only written by the call's last step).  Any split of K steps
+    into calls must reproduce K self-contained `pnmol_filter_step`s: read-outs, scalars, final covariance -- up to the
+    rounding of the predict, which the two paths contract into FMAs differently (observed: 1e-20 on entries of size
+    1e-2)."""
+    dt = 2.0 ** -6
+    K = sum(splits)
+    pde, solver, _, _ = make_pair(N, 2, dt, K)
+    s0 = solver.initialize(pde)
+    flt = solver._device_filter
+    solver._ensure_error_model(pde, dt)
+    single = flt.new_state()
+    single.set(pde.t0, s0.y.mean, s0.y.cov)
+    ref_means, ref_sig = [], []
+    cur = single
+    for _ in range(K):
+        cur, info, _ = flt.step(cur, dt)
+        ref_means.append(cur.mean()[0].copy())
+        ref_sig.append(info.diffusion_squared_local)
+    loop = flt.new_state()
+    loop.set(pde.t0, s0.y.mean, s0.y.cov)
+    means, sig = [], []
+    for k in splits:
+        m, s, infos = flt.steps(loop, k, dt)
+        means.extend(m)
+        sig.extend(o.diffusion_squared_local for o in infos)
+        assert np.array_equal(loop.mean()[0], m[-1])          # the state is complete after every call
+    ref_means = np.array(ref_means)
+    np.testing.assert_allclose(np.array(means), ref_means, rtol=1e-10, atol=1e-14 * np.abs(ref_means).max())
+    np.testing.assert_allclose(sig, ref_sig, rtol=1e-9)
+    c_ref = cur.cov()
+    np.testing.assert_allclose(loop.cov(), c_ref, rtol=1e-7, atol=1e-11 * np.abs(c_ref).max())
+    np.testing.assert_allclose(loop.marginal_var(), cur.marginal_var(), rtol=1e-7, atol=1e-11 * np.abs(c_ref).max())
