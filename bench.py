@@ -68,7 +68,19 @@ def cpu_baseline(seconds_budget=20.0):
         cores = max([t.get("num_threads", 1) for t in threadpool_info()] or [1])   # BLAS threads actually used
     except Exception:
         cores = os.cpu_count()
-    return {"value": n / el, "unit": "steps/s", "cores": cores, "kind": "port",
+    # beside it: the same step in covariance/Cholesky form with LAPACK potrf/trsm and dense GEMMs -- what
+    # the CPU does once the QR formulation's extra work is removed (a few steps are enough, it is ~10x faster)
+    cov_rate = None
+    try:
+        mean, cov, t = state.y.mean, state.y.cov_sqrtm @ state.y.cov_sqrtm.T, state.t
+        t1, m = time.perf_counter(), 0
+        while m < 8 and time.perf_counter() - t1 < 6.0:
+            mean, cov, _, _ = o.covariance_form_step(s, pde, mean, cov, DT, t)
+            t, m = t + DT, m + 1
+        cov_rate = m / (time.perf_counter() - t1)
+    except Exception:
+        pass
+    return {"value": n / el, "unit": "steps/s", "cores": cores, "kind": "port", "covariance_form_value": cov_rate,
             "sample": f"{n} steps of the N={MESH_N}, nu={NU} workload after 1 warm-up step; NumPy/SciPy "
                       f"(LAPACK, threaded BLAS on the CPUs the container allows), square-root form as written"}
 
