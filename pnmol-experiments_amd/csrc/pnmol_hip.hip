@@ -967,6 +967,7 @@ __device__ __forceinline__ void sweep_downdate_role(SweepLds& L, const DowndateA
                 for (int b = 0; b < N; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-fa[a].v[s], fb[b].v[s], acc[a][b], 0, 0, 0);
     }
+    SWEEP_STAMP(1);
     // epilogue: the tile, diag(P), and (J != K) the mirror image, transposed through wave-private LDS so that it
     // leaves as 128-byte rows; in the constant-step loop also (or, except for the last step, instead) the next
     // step's predicted covariance
@@ -1023,6 +1024,7 @@ __device__ __forceinline__ void sweep_downdate_role(SweepLds& L, const DowndateA
                 put_block(dd.Pnext, pn, (long)a * dd.dp + J * NB + qr * 16, (long)b * dd.dp + K * NB + qc * 16);
             }
     }
+    SWEEP_STAMP(2);
     // The vector ops of the step ride at the end of this role (rows [pair * vrows, +vrows) of vecops_rows): by now the
     // whole sweep is finished or about to be; a row still waits for the row block it reads and for the r^T block.
     {
@@ -1060,7 +1062,13 @@ __global__ __launch_bounds__(256) void k_sweep(const double* __restrict__ G, dou
     __shared__ __attribute__((aligned(16))) SweepLds L;
     const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);  // w: wave-uniform (SGPR)
     const int wr = w >> 1, wc = w & 1, fr = l & 15, fk = l >> 4;
-    const int I = blockIdx.x;
+    // Block -> row block.  The r^T block (row block zb of the tall matrix) is dealt right behind the rows of S, before the
+    // rows of W and of Ls^-T, which wait for it at their end (vector ops): dependencies keep pointing to lower blocks.
+    int I = blockIdx.x;
+    {
+        const int zb = RT - CB - 1;
+        if (I >= CB && I <= zb) I = (I == CB) ? zb : I - 1;
+    }
     const bool chain = I < CB;
     int* frow = flags;            // [RT]  chain rows: tiles of the row published; other rows: steps completed
     int* fdiag = flags + RT;      // [CB]
@@ -1222,6 +1230,30 @@ __global__ __launch_bounds__(256) void k_sweep(const double* __restrict__ G, dou
         SWEEP_TRACE(j, 6);
     }
     if (!chain) {
+        if constexpr (FUSED) {
+            // The vector ops of the step for the rows this workgroup has just finished (m = m- - W r for a block of W,
+            // the |r|^2 / |Ls^-T z|^2 / z^T Sq^-1 z terms for a block of Ls^-T): they only wait for the r^T block.
+            const int RBW = RT - 2 * CB - 1, zb = CB + RBW;
+            if (I != zb) {
+                __syncthreads();  // wave 3 has drained this row block's last tile
+                if (tid == 0 && !L.dead) {
+                    for (int spins = 0; flag_ld(frow + zb) < CB; ++spins) {
+                        if (spins > SWEEP_SPIN_LIMIT || flag_ld(fabort)) {
+                            L.dead = 1;
+                            flag_st(fabort, 1);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                __syncthreads();
+                const long Dp = (long)RBW * NB;
+                const long row0 = (I < zb ? (long)(I - CB) * NB : Dp + (long)(I - zb - 1) * NB) + 8 * w;
+                const double* W = F + (long)ld * ld;
+                vecops_rows4(dd.va, W, ld, Dp, row0, row0 + 4, l);
+                vecops_rows4(dd.va, W, ld, Dp, row0 + 4, row0 + 8, l);
+            }
+        }
         if (tid == 0 && L.dead) atomicMin(info, -2);
         SWEEP_STAMP(5);
         return;
@@ -1702,7 +1734,7 @@ int launch_step(pnmol_filter* f, const double* Pin, const double* min, double fr
         // K3'+K4: the whole sweep as one dataflow launch (one workgroup per 32-row block) with the covariance
         // down-date riding along (one workgroup per pair of 32-point tiles), then the vector ops
         const int t32 = dp / NB, pairs = t32 * (t32 + 1) / 2;
-        dd.vrows = (int)((Dp + mp + pairs - 1) / pairs);  // the vector ops ride at the end of the down-date workgroups
+        dd.vrows = 0;  // (the vector ops are done by the row-block workgroups of the sweep themselves)
         if constexpr (N <= 3)
             k_sweep<N, true><<<f->RT + pairs, 256, 0, st>>>(f->G, f->F, f->Linv, mp, f->CB, f->RT, f->flags, f->info, f->ctr, dd,
                                                             f->flags + f->RT + f->CB + 1, f->hs_scratch);

@@ -34,6 +34,9 @@ nd = int((st[RT:256, 0] > 0).sum())
 if nd:
     e2, s2 = us(st[RT:RT + nd, 5]), us(st[RT:RT + nd, 0])
     print(f"down-date WGs {nd}: start min/max {s2.min():.2f}/{s2.max():.2f}  end min/median/max {e2.min():.2f}/{np.median(e2):.2f}/{e2.max():.2f}")
+    m1, m2 = us(st[RT:RT + nd, 1]), us(st[RT:RT + nd, 2])
+    print(f"  last block done min/median/max {m1.min():.2f}/{np.median(m1):.2f}/{m1.max():.2f}; epilogue stores issued "
+          f"{np.median(m2 - m1):.2f} us later (median), vector ops + exit {np.median(e2 - m2):.2f} us")
 
 print("per-step trace of WG 16 (us): step-start, row[j] seen, S_j done(barrier), row[j+1] seen, partial done, diag seen, step end")
 for j in range(CB - 1):
