@@ -465,7 +465,9 @@ __device__ __forceinline__ void front_block(const double* __restrict__ Ppred, do
     }
     if (y < Dp + mp) {
         const int ip = (int)(y - Dp);
-        if (i < mp) {
+        // Only the block-lower part of S is ever read (a row block of the sweep uses its tiles up to the diagonal one,
+        // and inside a diagonal tile the entries right of the diagonal do not influence the factor): skip the rest.
+        if (i < mp && i < (ip / NB + 1) * NB) {
             double v;
             if (narrow && ip < mm.m && i < mm.m) {
                 HRow rr, rc;
@@ -481,6 +483,12 @@ __device__ __forceinline__ void front_block(const double* __restrict__ Ppred, do
     }
     const long q = y - Dp - mp;
     if (i < mp) G[((long)mp + Dp + NB + q) * mp + i] = (q == i) ? 1.0 : 0.0;
+}
+
+// the identity block of G never changes (k_sweep only reads G): written once, at filter creation
+__global__ void k_set_identity(double* __restrict__ Gi, int mp) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < mp) Gi[(long)q * mp + q] = 1.0;
 }
 
 __global__ __launch_bounds__(256) void k_front(const double* __restrict__ Ppred, double* __restrict__ G,
@@ -1721,7 +1729,8 @@ int launch_step(pnmol_filter* f, const double* Pin, const double* min, double fr
         Pin, f->Ppred, f->Kg, c, dp, min, f->mpred, f->shift, f->G, f->zbuf, mm, f->ctr, f->flags, f->RT + f->CB + 1 + f->CB * f->CB);
     // K2: G = [S; P-H^T; z; I]  (STEADY: done by the previous step's k_readout launch)
     if (kind != STEP_STEADY)
-        k_front<<<dim3((mp + 255) / 256, (unsigned)(Dp + 2 * mp)), 256, 0, st>>>(f->Ppred, f->G, f->rdiag, f->Rdense, mm, Dp);
+        k_front<<<dim3((mp + 255) / 256, (unsigned)(Dp + mp + (f->sweep_mode == 0 ? mp : 0))), 256, 0, st>>>(
+            f->Ppred, f->G, f->rdiag, f->Rdense, mm, Dp);  // (the per-panel path updates G in place: identity block too)
     const long rowI0 = (long)mp + Dp + NB;
     const double* W = f->F + (long)mp * mp;
     const bool have_sq = (f->Sqinv != nullptr && f->sq_dt == dt);
@@ -1767,8 +1776,8 @@ int launch_step(pnmol_filter* f, const double* Pin, const double* min, double fr
                                                     record ? f->rec_stds : nullptr, nordsieck_scale(f->nu, 0, dt), f->d,
                                                     f->part, f->rec, mp, f->ctr, ra, f->tickets, (int)rblocks, f->Ppred, f->rdiag,
                                                     f->Rdense);
-    else  // + the next step's vector predict (1 block) and k_front ((mp/256 rounded up) x (Dp + 2 mp) blocks)
-        k_readout<N, true><<<rblocks + 1 + (unsigned)(((mp + 255) / 256) * (Dp + 2 * mp)), 256, sizeof(double) * Dp, st>>>(
+    else  // + the next step's vector predict (1 block) and k_front ((mp/256 rounded up) x (Dp + mp) blocks)
+        k_readout<N, true><<<rblocks + 1 + (unsigned)(((mp + 255) / 256) * (Dp + mp)), 256, sizeof(double) * Dp, st>>>(
             mout, varout, record ? f->rec_means : nullptr, record ? f->rec_stds : nullptr, nordsieck_scale(f->nu, 0, dt),
             f->d, f->part, f->rec, mp, f->ctr, ra, f->tickets, (int)rblocks, f->Ppred, f->rdiag, f->Rdense);
     hipError_t e = hipGetLastError();
@@ -1939,7 +1948,8 @@ int run_error_model_sweep(pnmol_filter* f, const MeasModel& mm) {
     hipStream_t st = f->ctx->stream;
     const int mp = f->mp;
     const long Dp = f->Dp;
-    k_front<<<dim3((mp + 255) / 256, (unsigned)(Dp + 2 * mp)), 256, 0, st>>>(f->Qfull, f->G, f->rdiag, f->Rdense, mm, Dp);
+    k_front<<<dim3((mp + 255) / 256, (unsigned)(Dp + mp + (f->sweep_mode == 0 ? mp : 0))), 256, 0, st>>>(f->Qfull, f->G, f->rdiag,
+                                                                                                         f->Rdense, mm, Dp);
     DowndateArgs dd{};
     k_sweep<N, false><<<f->RT, 256, 0, st>>>(f->G, f->F, f->Linv, mp, f->CB, f->RT, f->flags, f->info_err, f->one, dd,
                                              f->flags + f->RT + f->CB + 1, f->hs_scratch);
@@ -2128,6 +2138,8 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
     }
     FCHK(hipMemset(f->shift, 0, sizeof(double) * mp));
     FCHK(hipMemset(f->G, 0, sizeof(double) * tall));
+    k_set_identity<<<(mp + 255) / 256, 256>>>(f->G + ((size_t)mp + Dp + NB) * mp, mp);
+    FCHK(hipDeviceSynchronize());
     FCHK(hipMemset(f->F, 0, sizeof(double) * tall));
     FCHK(hipMemset(f->var, 0, sizeof(double) * Dp));
     FCHK(hipMemset(f->tmpP, 0, sizeof(double) * (size_t)Dp * Dp));
