@@ -93,6 +93,11 @@ int pnmol_state_set(pnmol_state* s, double t, const double* mean_nd, const doubl
 int pnmol_state_get_time(const pnmol_state* s, double* t);
 int pnmol_state_get_mean(const pnmol_state* s, double* mean_nd);       /* (n,d)            */
 int pnmol_state_get_cov(const pnmol_state* s, double* cov_DD);         /* (D,D) F-order    */
+/* The lower-triangular Cholesky factor C of the covariance, C C^T = cov, (D,D) in the F-flattened order -- the
+ * canonical representative (positive diagonal) of what the reference carries as `cov_sqrtm` (base/rv.py:9-14; its
+ * QR factors differ from it by column signs only).  Computed on the device by the step's sweep kernel; a direction
+ * of exactly zero variance (noise-free Dirichlet node) gives a zero column.  -3 if cov is not PSD. */
+int pnmol_state_get_cov_sqrtm(const pnmol_state* s, double* C_DD);
 /* diag(cov) as (n,d): what experiments/figure1.py:76-80 reads out (`stds**2`)            */
 int pnmol_state_get_marginal_var(const pnmol_state* s, double* var_nd);
 

@@ -1884,6 +1884,21 @@ int prepare_graphs(pnmol_filter* f, pnmol_state* s, int k, double dt, hipGraphEx
     return rc;
 }
 
+// Covariance in the reference's state order (index j n + a, raw coordinates) as a (Dq x Dq) matrix padded with the
+// identity: input of the on-device Cholesky behind pnmol_state_get_cov_sqrtm.
+__global__ __launch_bounds__(256) void k_cov_reference_order(const double* __restrict__ P, double* __restrict__ Gc, int n,
+                                                             int d, int dp, long Dq, const double* __restrict__ sc) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= Dq * Dq) return;
+    const long r = e / Dq, c = e % Dq, D = (long)n * d, Dp = (long)n * dp;
+    double v = (r == c) ? 1.0 : 0.0;
+    if (r < D && c < D) {
+        const int j = (int)(r / n), a = (int)(r % n), k = (int)(c / n), b = (int)(c % n);
+        v = sc[a] * sc[b] * P[((long)a * dp + j) * Dp + (long)b * dp + k];
+    }
+    Gc[e] = v;
+}
+
 // Per-call results go to the host through a KERNEL that writes the mapped pinned staging buffer: one launch instead
 // of four hipMemcpyAsync calls (no SDMA queue, no runtime copy path inside the step loop).
 __global__ __launch_bounds__(256) void k_copy_out(const double* __restrict__ rec, const double* __restrict__ means,
@@ -1941,6 +1956,15 @@ void fill_out(const pnmol_filter* f, const double* rec, int info, double t_new, 
     o->diffusion_squared_local = rec[1] / f->m;
     o->error_sigma2 = have_sq ? rec[2] / f->m : std::nan("");
     o->info = (info >= f->mp) ? -1 : info;
+}
+
+template <int N>
+int run_cov_sqrtm_sweep(pnmol_filter* f, const double* Gc, double* Fc, double* Linvc, int Dq) {
+    DowndateArgs dd{};
+    const int cb = Dq / NB;
+    k_sweep<N, false><<<cb, 256, 0, f->ctx->stream>>>(Gc, Fc, Linvc, Dq, cb, cb, f->flags, f->info_err, f->one, dd,
+                                                      f->flags + 2 * cb + 1, f->hs_scratch);
+    return 0;
 }
 
 template <int N>
@@ -2390,6 +2414,73 @@ int pnmol_state_get_mean(const pnmol_state* s, double* mean_nd) {
     frame_scales(s, sc);
     for (int a = 0; a < f->n; ++a)
         for (int j = 0; j < f->ds; ++j) mean_nd[(size_t)a * f->ds + j] = sc[a] * hm[(size_t)a * f->dp + j];
+    return 0;
+}
+
+int pnmol_state_get_cov_sqrtm(const pnmol_state* s, double* C_DD) {
+    if (!s || !C_DD) return -1;
+    pnmol_filter* f = s->f;
+    pnmol_ctx* ctx = f->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int n = f->n, d = f->ds;
+    const long D = (long)n * d;
+    const int Dq = round_up((int)D, NB), cb = Dq / NB;
+    if (2 * cb + 1 > f->RT + f->CB + 1 + f->CB * f->CB) {
+        ctx->err = "pnmol_state_get_cov_sqrtm: flag buffer too small for this shape";
+        return -1;
+    }
+    double *Gc = nullptr, *Fc = nullptr, *Lc = nullptr, *dsc = nullptr;
+    hipError_t e = hipMalloc(&Gc, sizeof(double) * (size_t)Dq * Dq);
+    if (e == hipSuccess) e = hipMalloc(&Fc, sizeof(double) * (size_t)Dq * Dq);
+    if (e == hipSuccess) e = hipMalloc(&Lc, sizeof(double) * (size_t)cb * NB * NB);
+    if (e == hipSuccess) e = hipMalloc(&dsc, sizeof(double) * MAXN);
+    if (e == hipSuccess && !f->one) {
+        e = hipMalloc(&f->one, sizeof(int));
+        if (e == hipSuccess) e = hipMalloc(&f->info_err, sizeof(int));
+        const int h1 = 1;
+        if (e == hipSuccess) e = hipMemcpy(f->one, &h1, sizeof(int), hipMemcpyHostToDevice);
+    }
+    int rc = 0, inf = 0;
+    std::vector<double> hF;
+    if (e == hipSuccess) {
+        double sc[MAXN];
+        frame_scales(s, sc);
+        e = hipMemcpy(dsc, sc, sizeof(double) * MAXN, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemsetAsync(Fc, 0, sizeof(double) * (size_t)Dq * Dq, st);
+        if (e == hipSuccess) e = hipMemsetAsync(f->flags, 0, sizeof(int) * (2 * cb + 1), st);
+        if (e == hipSuccess) e = hipMemsetAsync(f->info_err, 0x7f, sizeof(int), st);
+        if (e == hipSuccess) {
+            k_cov_reference_order<<<(unsigned)(((long)Dq * Dq + 255) / 256), 256, 0, st>>>(s->P, Gc, n, d, f->dp, Dq, dsc);
+            switch (n) {
+                case 2: run_cov_sqrtm_sweep<2>(f, Gc, Fc, Lc, Dq); break;
+                case 3: run_cov_sqrtm_sweep<3>(f, Gc, Fc, Lc, Dq); break;
+                case 4: run_cov_sqrtm_sweep<4>(f, Gc, Fc, Lc, Dq); break;
+                default: rc = -1;
+            }
+            hF.resize((size_t)Dq * Dq);
+            e = hipMemcpyAsync(hF.data(), Fc, sizeof(double) * hF.size(), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(&inf, f->info_err, sizeof(int), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e == hipSuccess) e = hipGetLastError();
+        }
+    }
+    for (void* p : {(void*)Gc, (void*)Fc, (void*)Lc, (void*)dsc})
+        if (p) (void)hipFree(p);
+    if (e != hipSuccess) {
+        ctx->err = std::string("pnmol_state_get_cov_sqrtm: ") + hipGetErrorString(e);
+        return -2;
+    }
+    if (rc != 0) return rc;
+    if (inf == -2) {
+        ctx->err = "pnmol_state_get_cov_sqrtm: a dependency wait timed out";
+        return -2;
+    }
+    if (inf < Dq) {
+        ctx->err = "pnmol_state_get_cov_sqrtm: covariance not positive semi-definite at pivot " + std::to_string(inf);
+        return -3;
+    }
+    for (long r = 0; r < D; ++r) std::memcpy(C_DD + r * D, &hF[(size_t)r * Dq], sizeof(double) * D);
     return 0;
 }
 

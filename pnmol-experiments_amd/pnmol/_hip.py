@@ -63,6 +63,7 @@ SYMBOLS = {
     "pnmol_state_set": (ctypes.c_int, [_vp, ctypes.c_double, _c_double_p, _c_double_p]),
     "pnmol_state_get_time": (ctypes.c_int, [_vp, _c_double_p]),
     "pnmol_state_get_mean": (ctypes.c_int, [_vp, _c_double_p]),
+    "pnmol_state_get_cov_sqrtm": (ctypes.c_int, [_vp, _c_double_p]),
     "pnmol_state_get_cov": (ctypes.c_int, [_vp, _c_double_p]),
     "pnmol_state_get_marginal_var": (ctypes.c_int, [_vp, _c_double_p]),
     "pnmol_filter_step": (ctypes.c_int, [_vp, _vp, ctypes.c_double, _vp, ctypes.POINTER(StepOut), _c_double_p]),
@@ -289,6 +290,13 @@ class State:
     def marginal_var(self):
         out = np.empty((self.filter.n, self.filter.ds))
         self.ctx.check(self.lib.pnmol_state_get_marginal_var(self.handle, _dp(out)), "pnmol_state_get_marginal_var")
+        return out
+
+    def cov_sqrtm(self):
+        """Lower-triangular Cholesky factor of the covariance (device Cholesky), reference state order."""
+        D = self.filter.n * self.filter.ds
+        out = np.empty((D, D))
+        self.ctx.check(self.lib.pnmol_state_get_cov_sqrtm(self.handle, _dp(out)), "pnmol_state_get_cov_sqrtm")
         return out
 
     def cov(self):

@@ -23,7 +23,7 @@ def factor_of(cov):
 class DeviceMultivariateNormal:
     """Same attribute surface as `MultivariateNormal`, covariance resident on the GPU.
 
-    `mean` is a host (n, d) array; `cov`, `cov_sqrtm`, `marginal_var` are fetched / derived on demand.
+    `mean` is a host (n, d) array; `cov`, `cov_sqrtm`, `marginal_var` are fetched / computed on the device on demand.
     """
 
     def __init__(self, mean, device_state):
@@ -41,8 +41,11 @@ class DeviceMultivariateNormal:
 
     @property
     def cov_sqrtm(self):
+        """Lower-triangular Cholesky factor of the covariance, computed on the device on first use (the reference
+        carries a QR-derived lower-triangular factor with arbitrary column signs; this is its positive-diagonal
+        representative; a direction of exactly zero variance gives a zero column)."""
         if self._cov_sqrtm is None:
-            self._cov_sqrtm = factor_of(self.cov)
+            self._cov_sqrtm = self.device_state.cov_sqrtm()
         return self._cov_sqrtm
 
     def _replace(self, **kw):

@@ -5,7 +5,8 @@ covariance (Cholesky) form that the reference's own tests prove equivalent to it
 (tests/test_base/test_sqrt.py:48-78).  There is no CPU implementation of the step in this package.
 
 Documented deviations from the reference's numbers:
-  * `cov_sqrtm` is a (non-triangular) factor of the same covariance; only C C^T is comparable.
+  * `cov_sqrtm` is the lower-triangular Cholesky factor of the same covariance (device Cholesky); the reference's QR
+    factor differs by column signs, and arbitrarily where a pivot is exactly zero (noise-free Dirichlet nodes).
   * `diffusion_squared_local`: the reference evaluates |R1^-1 z|^2 / m with the QR factor R1 of the
     innovation (white.py:125), whose row signs LAPACK chooses from the data; here the same formula is
     evaluated with the Cholesky factor (positive diagonal).  `last_step_info.sigma2_whitened` holds

@@ -310,3 +310,35 @@ def test_loop_steps_match_single_steps(hip_ctx, N, splits):
     c_ref = cur.cov()
     np.testing.assert_allclose(loop.cov(), c_ref, rtol=1e-7, atol=1e-11 * np.abs(c_ref).max())
     np.testing.assert_allclose(loop.marginal_var(), cur.marginal_var(), rtol=1e-7, atol=1e-11 * np.abs(c_ref).max())
+
+
+@pytest.mark.parametrize("N,nu,bcond", [(20, 2, "neumann"), (40, 1, "dirichlet"), (64, 2, "dirichlet")])
+def test_cov_sqrtm_is_the_cholesky_factor(hip_ctx, N, nu, bcond):
+    """`state.y.cov_sqrtm` (pnmol_state_get_cov_sqrtm: device Cholesky of the covariance in the reference's state
+    order) is lower triangular with non-negative diagonal, reproduces the covariance, and equals the oracle's QR factor
+    (base/sqrt.py:33-73) after fixing the latter's column signs -- where the factor is well determined (columns whose
+    pivot is not at the rounding level of the covariance)."""
+    dt, K = 2.0 ** -6, 4
+    pde, solver, opde, osolver = make_pair(N, nu, dt, K, bcond=bcond)
+    sol, osol = solver.solve(pde), osolver.solve(opde)
+    C = sol.cov_sqrtm[-1]
+    cov = sol._ys[-1].cov
+    assert np.array_equal(C, np.tril(C)) and np.all(np.diag(C) >= 0.0)
+    # (pivots below 1e-13 of their diagonal entry are dropped as zero columns: entries change at the 1e-8 relative level)
+    np.testing.assert_allclose(C @ C.T, cov, rtol=1e-6, atol=1e-10 * np.abs(cov).max())
+    Co = osol.cov_sqrtm[-1]
+    Co = Co * np.where(np.diag(Co) < 0, -1.0, 1.0)[None, :]              # column signs of the QR factor
+    ocov = Co @ Co.T
+    np.testing.assert_allclose(cov, ocov, rtol=1e-3, atol=1e-7 * np.abs(ocov).max())
+    # Columns whose pivot is significant on the scale of its derivative class (index c % n in the F order).  Where the
+    # pivot is lost (noise-free boundary nodes and what they determine) the factorisation is not unique: the QR factor
+    # keeps an arbitrary direction there, the Cholesky factor a zero column -- same C C^T.
+    n = nu + 1
+    dvar = np.diag(ocov)
+    cls_max = np.array([dvar[a::n].max() for a in range(n)])
+    well = np.diag(Co) ** 2 > 1e-4 * cls_max[np.arange(dvar.size) % n]
+    first_bad = np.flatnonzero(~well)[0] if (~well).any() else well.size
+    if bcond == "neumann":                      # (Dirichlet: the very first node is noise-free -> nothing is unique)
+        assert first_bad >= n                   # columns behind a lost pivot inherit its arbitrariness
+    for c in range(first_bad):
+        np.testing.assert_allclose(C[:, c], Co[:, c], rtol=0, atol=1e-3 * np.abs(Co[:, c]).max())
