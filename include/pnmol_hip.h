@@ -96,7 +96,10 @@ int pnmol_state_get_cov(const pnmol_state* s, double* cov_DD);         /* (D,D) 
 /* The lower-triangular Cholesky factor C of the covariance, C C^T = cov, (D,D) in the F-flattened order -- the
  * canonical representative (positive diagonal) of what the reference carries as `cov_sqrtm` (base/rv.py:9-14; its
  * QR factors differ from it by column signs only).  Computed on the device by the step's sweep kernel; a direction
- * of exactly zero variance (noise-free Dirichlet node) gives a zero column.  -3 if cov is not PSD. */
+ * whose pivot falls below 1e-13 of its diagonal entry (noise-free Dirichlet node, numerically deterministic
+ * combinations) gives a zero column: diag(C C^T) stays exact to rounding, the off-diagonal entries of such a direction j
+ * are lost, |(C C^T - cov)_ij| <= sqrt(c_ii * 1e-13 c_jj).  Never fails on indefiniteness (the covariance of the
+ * recursion is PSD only up to rounding); -3 only for NaN. */
 int pnmol_state_get_cov_sqrtm(const pnmol_state* s, double* C_DD);
 /* diag(cov) as (n,d): what experiments/figure1.py:76-80 reads out (`stds**2`)            */
 int pnmol_state_get_marginal_var(const pnmol_state* s, double* var_nd);

@@ -1066,7 +1066,7 @@ __device__ __forceinline__ void sweep_downdate_role(SweepLds& L, const DowndateA
 template <int N, bool FUSED, bool CHAINHELP = FUSED>
 __global__ __launch_bounds__(256) void k_sweep(const double* __restrict__ G, double* F, double* Linv, int ld, int CB,
                                                int RT, int* flags, int* info_base, const int* __restrict__ ctr,
-                                               DowndateArgs dd, int* claim, double* hs_scratch) {
+                                               DowndateArgs dd, int* claim, double* hs_scratch, int lenient) {
     __shared__ __attribute__((aligned(16))) SweepLds L;
     const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);  // w: wave-uniform (SGPR)
     const int wr = w >> 1, wc = w & 1, fr = l & 15, fk = l >> 4;
@@ -1114,6 +1114,9 @@ __global__ __launch_bounds__(256) void k_sweep(const double* __restrict__ G, dou
     __syncthreads();
     SWEEP_STAMP(0);
     if (chain) smax = fmax(fmax(L.red[0], L.red[1]), fmax(L.red[2], L.red[3]));
+    // lenient (factor of a covariance that is PSD only up to the rounding of the filter recursion): a non-positive pivot
+    // is a dropped direction, never an error -- only NaN is
+    if (lenient) smax = __builtin_inf();
 
     const long rowC = (long)I * NB + wr * 16 + fk;  // first of my four C-layout rows (stride 4)
     const int colC = wc * 16 + fr;
@@ -1746,12 +1749,12 @@ int launch_step(pnmol_filter* f, const double* Pin, const double* min, double fr
         dd.vrows = 0;  // (the vector ops are done by the row-block workgroups of the sweep themselves)
         if constexpr (N <= 3)
             k_sweep<N, true><<<f->RT + pairs, 256, 0, st>>>(f->G, f->F, f->Linv, mp, f->CB, f->RT, f->flags, f->info, f->ctr, dd,
-                                                            f->flags + f->RT + f->CB + 1, f->hs_scratch);
+                                                            f->flags + f->RT + f->CB + 1, f->hs_scratch, 0);
     } else {
         if (f->sweep_mode == 1) {
             // K3': the sweep alone as one dataflow launch
             k_sweep<N, false><<<f->RT, 256, 0, st>>>(f->G, f->F, f->Linv, mp, f->CB, f->RT, f->flags, f->info, f->ctr, dd,
-                                                     f->flags + f->RT + f->CB + 1, f->hs_scratch);
+                                                     f->flags + f->RT + f->CB + 1, f->hs_scratch, 0);
         } else {
             k_diag0<<<1, 128, 0, st>>>(f->G, f->F, f->Linv, mp, f->info, f->sdiag, f->ctr);
             // K3: right-looking sweep, one launch per 32-column panel
@@ -1963,7 +1966,7 @@ int run_cov_sqrtm_sweep(pnmol_filter* f, const double* Gc, double* Fc, double* L
     DowndateArgs dd{};
     const int cb = Dq / NB;
     k_sweep<N, false><<<cb, 256, 0, f->ctx->stream>>>(Gc, Fc, Linvc, Dq, cb, cb, f->flags, f->info_err, f->one, dd,
-                                                      f->flags + 2 * cb + 1, f->hs_scratch);
+                                                      f->flags + 2 * cb + 1, f->hs_scratch, 1);
     return 0;
 }
 
@@ -1976,7 +1979,7 @@ int run_error_model_sweep(pnmol_filter* f, const MeasModel& mm) {
                                                                                                          f->Rdense, mm, Dp);
     DowndateArgs dd{};
     k_sweep<N, false><<<f->RT, 256, 0, st>>>(f->G, f->F, f->Linv, mp, f->CB, f->RT, f->flags, f->info_err, f->one, dd,
-                                             f->flags + f->RT + f->CB + 1, f->hs_scratch);
+                                             f->flags + f->RT + f->CB + 1, f->hs_scratch, 0);
     return 0;
 }
 
