@@ -97,7 +97,7 @@ int pnmol_state_get_cov(const pnmol_state* s, double* cov_DD);         /* (D,D) 
  * canonical representative (positive diagonal) of what the reference carries as `cov_sqrtm` (base/rv.py:9-14; its
  * QR factors differ from it by column signs only).  Computed on the device by the step's sweep kernel; a direction
  * whose pivot falls below 1e-13 of its diagonal entry (noise-free Dirichlet node, numerically deterministic
- * combinations) gives a zero column: diag(C C^T) stays exact to rounding, the off-diagonal entries of such a direction j
+ * combinations) gives a zero column: diag(C C^T) stays accurate (1e-6 relative or better), the off-diagonal entries of such a direction j
  * are lost, |(C C^T - cov)_ij| <= sqrt(c_ii * 1e-13 c_jj).  Never fails on indefiniteness (the covariance of the
  * recursion is PSD only up to rounding); -3 only for NaN. */
 int pnmol_state_get_cov_sqrtm(const pnmol_state* s, double* C_DD);
