@@ -107,7 +107,8 @@ def limit_blas_threads():
     try:
         import scipy.linalg  # noqa: F401
         from threadpoolctl import threadpool_limits
-        threadpool_limits(limits=cpu_quota())
+        local_ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))   # ranks of this node share the quota
+        threadpool_limits(limits=max(1, cpu_quota() // local_ranks))
     except Exception:
         pass
 
