@@ -767,23 +767,26 @@ __device__ __forceinline__ void vecops_rows(const VecArgs& va, const double* __r
     }
 }
 
-// rows [r0, r1), r1 - r0 <= 4, of vecops_rows by one wave; same per-row lane-strided summation, but the loads of up
-// to 4 rows x 4 column slices are issued before the first is used
-__device__ __forceinline__ void vecops_rows4(const VecArgs& va, const double* __restrict__ W, int mp, long Dp, long r0,
+// rows [r0, r1), r1 - r0 <= R, of vecops_rows by one wave; same per-row lane-strided summation, but the loads of up
+// to R rows x 4 column slices are issued before the first is used
+template <int R>
+__device__ __forceinline__ void vecops_rowsR(const VecArgs& va, const double* __restrict__ W, int mp, long Dp, long r0,
                                              long r1, int l) {
-    double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
-    const double* src[4];
-    const double* src2[4];
-    bool isw[4];
+    double a[R], b[R];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < R; ++q) a[q] = b[q] = 0.0;
+    const double* src[R];
+    const double* src2[R];
+    bool isw[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
         const long row = min(r0 + q, r1 - 1);
         isw[q] = row < Dp;
         src[q] = isw[q] ? W + row * mp : va.LinvT + (row - Dp) * mp;
         src2[q] = (!isw[q] && va.Sqinv) ? va.Sqinv + (row - Dp) * mp : nullptr;
     }
     for (int i0 = l; i0 < mp; i0 += 256) {
-        double wv[4][4], sv[4][4], xv[4], zv[4];
+        double wv[R][4], sv[R][4], xv[4], zv[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int i = i0 + 64 * t;
@@ -791,7 +794,7 @@ __device__ __forceinline__ void vecops_rows4(const VecArgs& va, const double* __
             xv[t] = in ? va.r[i] : 0.0;
             zv[t] = in ? va.z[i] : 0.0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < R; ++q) {
                 wv[q][t] = in ? src[q][i] : 0.0;
                 sv[q][t] = (in && src2[q]) ? src2[q][i] : 0.0;
             }
@@ -799,13 +802,13 @@ __device__ __forceinline__ void vecops_rows4(const VecArgs& va, const double* __
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < R; ++q) {
                 a[q] += wv[q][t] * (isw[q] ? xv[t] : zv[t]);
                 b[q] += sv[q][t] * zv[t];
             }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < R; ++q) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             a[q] += __shfl_xor(a[q], o);
@@ -882,6 +885,11 @@ __device__ __forceinline__ int helper_share(int H, int t, int CB) {
     if (h >= H - 1 || t < h + 3) return 0;  // no helper for this row / helper not free that early
     const int kh = t - 1 - HELP_KMAX;
     return kh > 0 ? kh : 0;
+}
+
+__device__ __forceinline__ void vecops_rows4(const VecArgs& va, const double* __restrict__ W, int mp, long Dp, long r0,
+                                             long r1, int l) {
+    vecops_rowsR<4>(va, W, mp, Dp, r0, r1, l);
 }
 
 // Arguments of the covariance down-date role (workgroups RT .. RT + pairs - 1 of a fused launch)
@@ -1261,8 +1269,7 @@ __global__ __launch_bounds__(256) void k_sweep(const double* __restrict__ G, dou
                 const long Dp = (long)RBW * NB;
                 const long row0 = (I < zb ? (long)(I - CB) * NB : Dp + (long)(I - zb - 1) * NB) + 8 * w;
                 const double* W = F + (long)ld * ld;
-                vecops_rows4(dd.va, W, ld, Dp, row0, row0 + 4, l);
-                vecops_rows4(dd.va, W, ld, Dp, row0 + 4, row0 + 8, l);
+                vecops_rowsR<8>(dd.va, W, ld, Dp, row0, row0 + 8, l);
             }
         }
         if (tid == 0 && L.dead) atomicMin(info, -2);
