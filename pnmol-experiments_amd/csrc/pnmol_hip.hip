@@ -775,28 +775,34 @@ __device__ __forceinline__ void vecops_rowsR(const VecArgs& va, const double* __
     double a[R], b[R];
 #pragma unroll
     for (int q = 0; q < R; ++q) a[q] = b[q] = 0.0;
+    // All loads are unconditional (clamped index, weight 0 outside) so that they are issued back to back: with
+    // predicated loads the compiler emitted one exec-masked region per load and this latency-bound tail took 9-13 us.
     const double* src[R];
     const double* src2[R];
     bool isw[R];
+    double w2[R];
 #pragma unroll
     for (int q = 0; q < R; ++q) {
         const long row = min(r0 + q, r1 - 1);
         isw[q] = row < Dp;
         src[q] = isw[q] ? W + row * mp : va.LinvT + (row - Dp) * mp;
-        src2[q] = (!isw[q] && va.Sqinv) ? va.Sqinv + (row - Dp) * mp : nullptr;
+        const bool has2 = !isw[q] && va.Sqinv != nullptr;
+        src2[q] = has2 ? va.Sqinv + (row - Dp) * mp : src[q];  // (dummy: same row, weight 0)
+        w2[q] = has2 ? 1.0 : 0.0;
     }
     for (int i0 = l; i0 < mp; i0 += 256) {
         double wv[R][4], sv[R][4], xv[4], zv[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int i = i0 + 64 * t;
-            const bool in = i < mp;
-            xv[t] = in ? va.r[i] : 0.0;
-            zv[t] = in ? va.z[i] : 0.0;
+            const int ii = i < mp ? i : mp - 1;
+            const double in = i < mp ? 1.0 : 0.0;
+            xv[t] = in * va.r[ii];
+            zv[t] = in * va.z[ii];
 #pragma unroll
             for (int q = 0; q < R; ++q) {
-                wv[q][t] = in ? src[q][i] : 0.0;
-                sv[q][t] = (in && src2[q]) ? src2[q][i] : 0.0;
+                wv[q][t] = src[q][ii];
+                sv[q][t] = src2[q][ii];
             }
         }
 #pragma unroll
@@ -804,7 +810,7 @@ __device__ __forceinline__ void vecops_rowsR(const VecArgs& va, const double* __
 #pragma unroll
             for (int q = 0; q < R; ++q) {
                 a[q] += wv[q][t] * (isw[q] ? xv[t] : zv[t]);
-                b[q] += sv[q][t] * zv[t];
+                b[q] += w2[q] * sv[q][t] * zv[t];
             }
     }
 #pragma unroll
@@ -1254,6 +1260,7 @@ __global__ __launch_bounds__(256) void k_sweep(const double* __restrict__ G, dou
             // the |r|^2 / |Ls^-T z|^2 / z^T Sq^-1 z terms for a block of Ls^-T): they only wait for the r^T block.
             const int RBW = RT - 2 * CB - 1, zb = CB + RBW;
             if (I != zb) {
+                SWEEP_STAMP(1);
                 __syncthreads();  // wave 3 has drained this row block's last tile
                 if (tid == 0 && !L.dead) {
                     for (int spins = 0; flag_ld(frow + zb) < CB; ++spins) {
@@ -1269,6 +1276,7 @@ __global__ __launch_bounds__(256) void k_sweep(const double* __restrict__ G, dou
                 const long Dp = (long)RBW * NB;
                 const long row0 = (I < zb ? (long)(I - CB) * NB : Dp + (long)(I - zb - 1) * NB) + 8 * w;
                 const double* W = F + (long)ld * ld;
+                SWEEP_STAMP(2);
                 vecops_rowsR<8>(dd.va, W, ld, Dp, row0, row0 + 8, l);
             }
         }

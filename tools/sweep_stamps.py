@@ -30,6 +30,9 @@ RT = 2 * CB + 3 * dp // 32 + 1
 ends = us(st[CB:RT, 5])
 starts = us(st[CB:RT, 0])
 print(f"bulk WGs {RT-CB}: start min/max {starts.min():.2f}/{starts.max():.2f}  end min/max {ends.min():.2f}/{ends.max():.2f}")
+order = np.argsort(ends)[::-1][:6]
+print("  latest bulk blocks (physical index: loop end / r^T seen / end):", ", ".join(f"{CB + int(i)}: {us(st[CB + int(i)])[1]:.1f}/{us(st[CB + int(i)])[2]:.1f}/{ends[i]:.1f}" for i in order))
+print("  first W-row blocks:", ", ".join(f"{CB + 1 + i}: {us(st[CB + 1 + i])[1]:.1f}/{us(st[CB + 1 + i])[2]:.1f}/{ends[1 + i]:.1f}" for i in range(4)), f"; r^T block {CB}: end {ends[0]:.1f}")
 nd = int((st[RT:256, 0] > 0).sum())
 if nd:
     e2, s2 = us(st[RT:RT + nd, 5]), us(st[RT:RT + nd, 0])
