@@ -192,6 +192,23 @@ class WhiteNoise(_Kern):
         return self.output_scale**2 * np.all(X == Y, axis=-1)
 
 
+class _Stacked(_Kern):
+    """kernels.py:160-176: stack of kernels whose full Gram matrix is block diagonal (diagonal: concatenated)."""
+
+    def __init__(self, kernel_list):
+        self.kernel_list = list(kernel_list)
+
+    def __call__(self, X, Y):
+        grams = [k(X, Y) for k in self.kernel_list]
+        if np.shape(X) == np.shape(Y):
+            return np.concatenate(grams)
+        return scipy.linalg.block_diag(*grams)
+
+
+def duplicate(kernel, num):  # kernels.py:178-183
+    return _Stacked([kernel] * num)
+
+
 # --------------------------------------------------------------------------------------
 # Mesh (reference: mesh.py:75-184)
 # --------------------------------------------------------------------------------------
@@ -377,6 +394,75 @@ def spruce_budworm_1d_discretized(*, bbox=None, t0=0.0, tmax=10.0, diffusion_rat
     p.f = lambda _t, x: growth_rate * x * (1.0 - x)
     p.df = lambda _t, x: np.diag(growth_rate * (1.0 - 2.0 * x))
     return p
+
+
+def _system_discretized(*, f, df, y0_fun, diffusion_rates, bbox, t0, tmax, dx, kernel, stencil_size_interior,
+                        stencil_size_boundary, nugget_gram_matrix_fd):
+    """SystemDiscretizationMixIn.discretize_system (mixins.py:62-125) for SystemSemiLinearEvolutionNeumann
+    (problems.py:76-86): block-diagonal L, E_sqrtm (one scaled Laplacian per component), B, R_sqrtm."""
+    bbox = np.asarray([0.0, 1.0] if bbox is None else bbox, dtype=np.float64)
+    mesh = RectMesh.from_bbox_1d(bbox, step=dx)
+    kernel = kernel or SquareExponential()
+    L, E = fd_probabilistic_laplace(mesh, kernel, stencil_size_interior, stencil_size_boundary, nugget_gram_matrix_fd)
+    B, R = fd_probabilistic_neumann_1d(mesh, kernel, nugget_gram_matrix_fd)
+    n = len(diffusion_rates)
+    return HeatProblem(L=scipy.linalg.block_diag(*[r * L for r in diffusion_rates]),
+                       E_sqrtm=scipy.linalg.block_diag(*[r * E for r in diffusion_rates]),
+                       B=scipy.linalg.block_diag(*([B] * n)), R_sqrtm=scipy.linalg.block_diag(*([R] * n)),
+                       y0=np.asarray(y0_fun(mesh.points)).squeeze(), t0=t0, tmax=tmax, mesh_spatial=mesh, bbox=bbox,
+                       diffop_scale=tuple(diffusion_rates), bcond="neumann", f=f, df=df)
+
+
+def lotka_volterra_1d_discretized(*, bbox=None, t0=0.0, tmax=10.0, a=0.5, b=0.05, c=0.05, d=0.5, diffusion_scale_u=0.1,
+                                  diffusion_scale_v=0.1, dx=0.05, kernel=None, nugget_gram_matrix_fd=0.0,
+                                  stencil_size_interior=3, stencil_size_boundary=3):
+    """examples.py:181-248: u_t = D_u u_xx + a u - b u v,  v_t = D_v v_xx + c u v - d v, Neumann; state [u; v]."""
+
+    def f(_t, x):
+        u, v = np.split(np.asarray(x, dtype=np.float64), 2)
+        return np.concatenate((a * u - b * u * v, c * u * v - d * v))
+
+    def df(_t, x):  # jax.jacfwd of f (examples.py:232)
+        u, v = np.split(np.asarray(x, dtype=np.float64), 2)
+        return np.block([[np.diag(a - b * v), np.diag(-b * u)], [np.diag(c * v), np.diag(c * u - d)]])
+
+    def y0_fun(x):
+        return np.concatenate((5.0 * np.ones_like(x), 20.0 * np.exp(-(x ** 2))))
+
+    return _system_discretized(f=f, df=df, y0_fun=y0_fun, diffusion_rates=(diffusion_scale_u, diffusion_scale_v),
+                               bbox=bbox, t0=t0, tmax=tmax, dx=dx, kernel=kernel,
+                               stencil_size_interior=stencil_size_interior, stencil_size_boundary=stencil_size_boundary,
+                               nugget_gram_matrix_fd=nugget_gram_matrix_fd)
+
+
+def sir_1d_discretized(*, bbox=None, dx=0.05, t0=0.0, tmax=50.0, beta=0.3, gamma=0.07, N=1000.0, diffusion_rate_S=0.1,
+                       diffusion_rate_I=0.1, diffusion_rate_R=0.1, kernel=None, nugget_gram_matrix_fd=0.0,
+                       stencil_size_interior=3, stencil_size_boundary=3):
+    """examples.py:84-178: spatial SIR model, Neumann; state [S; I; R]."""
+    bb = np.asarray([0.0, 1.0] if bbox is None else bbox, dtype=np.float64)
+
+    def f(_t, x):
+        s, i, r = np.split(np.asarray(x, dtype=np.float64), 3)
+        tot = s + i + r
+        return np.concatenate((-beta * s * i / tot, beta * s * i / tot - gamma * i, gamma * i))
+
+    def df(_t, x):  # jax.jacfwd of f (examples.py:163)
+        s, i, r = np.split(np.asarray(x, dtype=np.float64), 3)
+        tot = s + i + r
+        g = beta * s * i / tot                       # infection term and its partial derivatives
+        gs, gi, gr = beta * i / tot - g / tot, beta * s / tot - g / tot, -g / tot
+        D, Z = np.diag, np.zeros((s.size, s.size))
+        return np.block([[D(-gs), D(-gi), D(-gr)], [D(gs), D(gi - gamma), D(gr)], [Z, D(gamma * np.ones_like(i)), Z]])
+
+    def y0_fun(x):
+        mid = 0.5 * (bb[1] + bb[0])
+        inf = 200.0 * np.exp(-((x - mid) ** 2) / 0.5 ** 2) + 1.0
+        return np.concatenate((N * np.ones_like(inf) - inf, inf, np.zeros_like(inf)))
+
+    return _system_discretized(f=f, df=df, y0_fun=y0_fun,
+                               diffusion_rates=(diffusion_rate_S, diffusion_rate_I, diffusion_rate_R), bbox=bbox, t0=t0,
+                               tmax=tmax, dx=dx, kernel=kernel, stencil_size_interior=stencil_size_interior,
+                               stencil_size_boundary=stencil_size_boundary, nugget_gram_matrix_fd=nugget_gram_matrix_fd)
 
 
 def heat_2d_dirichlet_discretized(*, nums=(8, 8), stencil_size_interior=5, stencil_size_boundary=5,

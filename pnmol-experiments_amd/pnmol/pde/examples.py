@@ -53,6 +53,90 @@ def heat_2d_dirichlet_discretized(*, nums=(64, 64), stencil_size_interior=5, ste
     return heat
 
 
+def sir_1d_discretized(*, bbox=None, dx=0.05, t0=0.0, tmax=50.0, beta=0.3, gamma=0.07, N=1000.0, diffusion_rate_S=0.1,
+                       diffusion_rate_I=0.1, diffusion_rate_R=0.1, kernel=None, nugget_gram_matrix_fd=0.0,
+                       stencil_size_interior=3, stencil_size_boundary=3):
+    """examples.py:84-124."""
+    sir = sir_1d(bbox=bbox, t0=t0, tmax=tmax, diffusion_rate_S=diffusion_rate_S, diffusion_rate_I=diffusion_rate_I,
+                 diffusion_rate_R=diffusion_rate_R, beta=beta, gamma=gamma, N=N)
+    mesh_spatial = mesh.RectangularMesh.from_bbox_1d(sir.bbox, step=dx)
+    if kernel is None:
+        kernel = kernels.SquareExponential()
+    sir.discretize_system(mesh_spatial=mesh_spatial, kernel=kernel, stencil_size_interior=stencil_size_interior,
+                          stencil_size_boundary=stencil_size_boundary, nugget_gram_matrix=nugget_gram_matrix_fd)
+    return sir
+
+
+def sir_1d(*, bbox=None, t0=0.0, tmax=50.0, diffusion_rate_S=0.1, diffusion_rate_I=0.1, diffusion_rate_R=0.1, beta=0.3,
+           gamma=0.07, N=1000.0):
+    """Spatial SIR model, state [S; I; R], Neumann boundary (examples.py:127-178); `df` is the closed-form Jacobian of
+    the reaction term (the reference differentiates it with jax.jacfwd)."""
+    if bbox is None:
+        bbox = [0.0, 1.0]
+    bbox = np.asarray(bbox, dtype=np.float64)
+
+    def y0_fun(x):
+        init_infectious = 200.0 * gaussian_bell_1d_centered(x, bbox, width=0.5) + 1.0
+        return np.concatenate((N * np.ones_like(init_infectious) - init_infectious, init_infectious,
+                               np.zeros_like(init_infectious)))
+
+    def f(_t, x):
+        s, i, r = np.split(np.asarray(x, dtype=np.float64), 3)
+        spatial_n = s + i + r
+        return np.concatenate((-beta * s * i / spatial_n, beta * s * i / spatial_n - gamma * i, gamma * i))
+
+    def df(_t, x):
+        s, i, r = np.split(np.asarray(x, dtype=np.float64), 3)
+        tot = s + i + r
+        g = beta * s * i / tot
+        gs, gi, gr = beta * i / tot - g / tot, beta * s / tot - g / tot, -g / tot
+        zero = np.zeros((s.size, s.size))
+        return np.block([[np.diag(-gs), np.diag(-gi), np.diag(-gr)], [np.diag(gs), np.diag(gi - gamma), np.diag(gr)],
+                         [zero, np.diag(gamma * np.ones_like(i)), zero]])
+
+    laplace = diffops.laplace()
+    return problems.SystemSemiLinearEvolutionNeumann(
+        diffop=(laplace, laplace, laplace), diffop_scale=(diffusion_rate_S, diffusion_rate_I, diffusion_rate_R),
+        bbox=bbox, t0=t0, tmax=tmax, y0_fun=y0_fun, f=f, df=df, df_diagonal=None)
+
+
+def lotka_volterra_1d_discretized(*, dx=0.05, kernel=None, nugget_gram_matrix_fd=0.0, stencil_size_interior=3,
+                                  stencil_size_boundary=3, **kwargs):
+    """examples.py:181-203."""
+    pde = lotka_volterra_1d(**kwargs)
+    mesh_spatial = mesh.RectangularMesh.from_bbox_1d(pde.bbox, step=dx)
+    if kernel is None:
+        kernel = kernels.SquareExponential()
+    pde.discretize_system(mesh_spatial=mesh_spatial, kernel=kernel, stencil_size_interior=stencil_size_interior,
+                          stencil_size_boundary=stencil_size_boundary, nugget_gram_matrix=nugget_gram_matrix_fd)
+    return pde
+
+
+def lotka_volterra_1d(*, bbox=None, t0=0.0, tmax=10.0, a=0.5, b=0.05, c=0.05, d=0.5, diffusion_scale_u=0.1,
+                      diffusion_scale_v=0.1):
+    """Predator-prey system u_t = D_u u_xx + a u - b u v, v_t = D_v v_xx + c u v - d v, state [u; v], Neumann boundary
+    (examples.py:206-248, the workload of experiments/figure4.py); closed-form Jacobian instead of jax.jacfwd."""
+    if bbox is None:
+        bbox = [0.0, 1.0]
+    bbox = np.asarray(bbox, dtype=np.float64)
+
+    def y0_fun(x):
+        return np.concatenate((5 * np.ones_like(x), 20.0 * gaussian_bell_1d(x)))
+
+    def f_lotka_volterra(_, x):
+        u, v = np.split(np.asarray(x, dtype=np.float64), 2)
+        return np.concatenate((a * u - b * u * v, c * u * v - d * v))
+
+    def df_lotka_volterra(_, x):
+        u, v = np.split(np.asarray(x, dtype=np.float64), 2)
+        return np.block([[np.diag(a - b * v), np.diag(-b * u)], [np.diag(c * v), np.diag(c * u - d)]])
+
+    laplace = diffops.laplace()
+    return problems.SystemSemiLinearEvolutionNeumann(
+        diffop=(laplace, laplace), diffop_scale=(diffusion_scale_u, diffusion_scale_v), bbox=bbox, t0=t0, tmax=tmax,
+        y0_fun=y0_fun, f=f_lotka_volterra, df=df_lotka_volterra, df_diagonal=None)
+
+
 def spruce_budworm_1d_discretized(*, bbox=None, t0=0.0, tmax=10.0, diffusion_rate=1.0, y0_fun=None, dx=0.1, kernel=None,
                                   nugget_gram_matrix_fd=0.0, stencil_size_interior=3, stencil_size_boundary=3,
                                   bcond="dirichlet", growth_rate=1.0):

@@ -45,3 +45,12 @@ class SemiLinearEvolutionDirichlet(mixins.IVPMixIn, mixins.NonLinearMixIn, mixin
 class SemiLinearEvolutionNeumann(mixins.IVPMixIn, mixins.NonLinearMixIn, mixins.DiscretizationMixIn,
                                  mixins.NeumannMixIn, PDE):
     pass
+
+
+class SystemLinearPDENeumann(mixins.SystemDiscretizationMixIn, mixins.NeumannMixIn, PDE):
+    """Systems of linear PDEs with Neumann boundary conditions (problems.py:70-73)."""
+
+
+class SystemSemiLinearEvolutionNeumann(mixins.IVPMixIn, mixins.NonLinearMixIn, mixins.IVPConversionSemiLinearMixIn,
+                                       mixins.SystemDiscretizationMixIn, mixins.SystemNeumannMixIn, PDE):
+    """Systems of semilinear, time-dependent PDEs with Neumann boundary conditions (problems.py:76-86)."""
