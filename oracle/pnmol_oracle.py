@@ -740,7 +740,7 @@ class WhiteNoiseEK1:
         return proposed, dt, info
 
     # ---- pdefilter.py:118-165
-    def solution_generator(self, pde, *, stop_at=None):
+    def solution_generator(self, pde, *, stop_at=None, progressbar=False):
         stopper = _TimeStopper(stop_at) if stop_at is not None else None
         state = self.initialize(pde)
         info = dict(num_f_evaluations=0, num_df_evaluations=0, num_df_diagonal_evaluations=0,
