@@ -33,7 +33,48 @@ def run(name, *, N, nu, dt, tmax, dx, bcond, prior):
     print(name, sol.t.shape, means.shape)
 
 
+# ---- f2/f3 solvers: semilinear, latent-force and system recipes (oracle output as above, same provenance) ----------
+MODEL_CASES = {
+    # name: (recipe, recipe kwargs, n components, latent, dt, steps, prior kernel name)
+    "oracle_spruce_white": ("spruce_budworm_1d_discretized", dict(dx=0.1), 1, False, 2.0 ** -4, 8, "SquareExponential"),
+    "oracle_heat_latent_neumann": ("heat_1d_discretized", dict(dx=0.1, bcond="neumann"), 1, True, 2.0 ** -5, 8,
+                                   "SquareExponential"),
+    "oracle_lv_white": ("lotka_volterra_1d_discretized", dict(dx=1.0 / 15), 2, False, 2.0 ** -5, 8, "Matern52"),
+    "oracle_lv_latent": ("lotka_volterra_1d_discretized", dict(dx=1.0 / 15), 2, True, 2.0 ** -5, 8, "Matern52"),
+    "oracle_sir_white": ("sir_1d_discretized", dict(dx=1.0 / 12), 3, False, 2.0 ** -3, 8, "Matern52"),
+}
+
+
+def build_model(mod, examples, latent_mod, white_mod, name):
+    """The same case in `mod` = the oracle or the product's host mirror (used by tests/test_golden.py too)."""
+    recipe, kw, ncomp, latent, dt, K, kname = MODEL_CASES[name]
+    pde = getattr(examples, recipe)(tmax=K * dt, **kw)
+    k = getattr(mod, kname)() + mod.WhiteNoise()
+    if ncomp > 1:
+        k = mod.duplicate(k, ncomp)
+    semilinear = recipe != "heat_1d_discretized"
+    return pde, k, latent, semilinear, dt
+
+
+def run_model(name):
+    pde, k, latent, semilinear, dt = build_model(o, o, None, None, name)
+    cls = o.LatentForceEK1 if latent else o.WhiteNoiseEK1
+    s = cls(num_derivatives=2, steprule=o.Constant(dt), spatial_kernel=k, semilinear=semilinear,
+            canonical_factor_signs=True)
+    sol = s.solve(pde)
+    if latent:
+        means, stds = o.read_mean_and_std_latent(sol, s.state_iwp.projection_matrix(0))
+    else:
+        means, stds = o.read_mean_and_std(sol, s.E0)
+    d = pde.y0.shape[0]
+    np.savez_compressed(pathlib.Path(__file__).parent / f"{name}.npz", t=sol.t, means=means[:, :d], stds=stds[:, :d],
+                        L=pde.L, y0=pde.y0, diffusion_squared_calibrated_canonical=sol.diffusion_squared_calibrated)
+    print(name, sol.t.shape, means.shape, float(np.abs(means).max()), float(stds.max()))
+
+
 if __name__ == "__main__":
+    for name in MODEL_CASES:
+        run_model(name)
     for bc in ("dirichlet", "neumann"):
         run(f"oracle_heat_smoke_{bc}", N=6, nu=2, dt=0.1, tmax=1.0, dx=0.2, bcond=bc, prior=o.SquareExponential() + o.WhiteNoise())
     run("oracle_heat_n32_nu1", N=32, nu=1, dt=2.0**-7, tmax=100 * 2.0**-7, dx=1.0 / 31, bcond="dirichlet",
