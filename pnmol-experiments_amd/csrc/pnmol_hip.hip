@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "pnmol_hip.h"
+#include "pnmol_internal.hpp"
 
 namespace {
 
@@ -1646,11 +1647,7 @@ static double nordsieck_scale(int nu, int a, double dt) {  // base/iwp.py:55-62
 
 }  // namespace
 
-struct pnmol_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    std::string err;
-};
+// struct pnmol_ctx: pnmol_internal.hpp
 
 struct pnmol_filter {
     pnmol_ctx* ctx = nullptr;

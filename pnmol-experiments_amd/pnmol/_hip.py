@@ -76,6 +76,8 @@ SYMBOLS = {
     "pnmol_filter_prepare_error_model": (ctypes.c_int, [_vp, ctypes.c_double]),
     "pnmol_filter_debug_read": (ctypes.c_int, [_vp, ctypes.c_int, _c_double_p, ctypes.c_long]),
     "pnmol_filter_dims": (ctypes.c_int, [_vp] + [ctypes.POINTER(ctypes.c_int)] * 5),
+    # include/pnmol_sqrt.h
+    "pnmol_qr_r": (ctypes.c_int, [_vp, _c_double_p, ctypes.c_int, ctypes.c_int, _c_double_p]),
 }
 
 _lib = None
@@ -137,6 +139,14 @@ class Context:
         if device not in cls._cache:
             cls._cache[device] = cls(device)
         return cls._cache[device]
+
+    def qr_r(self, A):
+        """R factor (upper, diag >= 0) of A on the device: `jnp.linalg.qr(A, mode="r")` (base/sqrt.py:21)."""
+        A = _f64(A)
+        rows, cols = A.shape
+        R = np.empty((cols, cols))
+        self.check(self.lib.pnmol_qr_r(self.handle, _dp(A), rows, cols, _dp(R)), "pnmol_qr_r")
+        return R
 
     def check(self, rc, what):
         if rc != 0:
