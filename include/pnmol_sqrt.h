@@ -20,6 +20,23 @@ extern "C" {
 /* R (cols x cols, upper triangular, diag >= 0) of A (rows x cols): `jnp.linalg.qr(A, mode="r")` as used at
  * base/sqrt.py:21, :66, :88.  rows < cols is allowed (A is zero-padded: R's trailing rows are then zero). */
 int pnmol_qr_r(pnmol_ctx* ctx, const double* A, int rows, int cols, double* R);
+/* device time (HIP events) of the factorisation inside the calling thread's last pnmol_qr_r / pnmol_sqrt_* call */
+int pnmol_qr_last_ms(float* ms);
+
+/* `propagate_cholesky_factor(S1, S2)` (base/sqrt.py:8-12) = `sqrtm_to_cholesky(vstack(S1^T, S2^T))` (:15-23): the lower
+ * triangular factor of S1 S1^T + S2 S2^T.  S1 (n,k1), S2 (n,k2) or NULL; chol_nn (n,n). */
+int pnmol_sqrt_propagate_cholesky_factor(pnmol_ctx* ctx, const double* S1, int n, int k1, const double* S2, int k2,
+                                         double* chol_nn);
+
+/* `update_sqrt(transition_matrix, cov_cholesky, meascov_sqrtm)` (base/sqrt.py:33-73): QR of
+ * [[C^T H^T, C^T], [E^T, 0]].  H (m,D), C (D,D), meascov_sqrtm E (m,m), m <= D.  Outputs (each may be NULL):
+ * C_new (D,D) = R3^T lower, gain (D,m) = (R1^-1 R2)^T, Sl (m,m) = R1^T lower.  A singular innovation matrix gives a
+ * non-finite gain, as `solve_triangular` does in the reference. */
+int pnmol_sqrt_update(pnmol_ctx* ctx, const double* H, int m, int D, const double* C, const double* meascov_sqrtm,
+                      double* C_new, double* gain, double* Sl);
+/* `update_sqrt_no_meascov(transition_matrix, cov_cholesky)` (base/sqrt.py:76-95) */
+int pnmol_sqrt_update_no_meascov(pnmol_ctx* ctx, const double* H, int m, int D, const double* C, double* C_new,
+                                 double* gain, double* Sl);
 
 #ifdef __cplusplus
 }

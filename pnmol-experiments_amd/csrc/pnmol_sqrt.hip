@@ -255,17 +255,117 @@ __global__ __launch_bounds__(256) void k_qr_apply(double* __restrict__ W, long l
     }
 }
 
-// host matrix (rows x cols, row-major, leading dimension lda) <-> padded work matrix
-__global__ void k_qr_extract(const double* __restrict__ W, long ld, int n, double* __restrict__ R, int transpose) {
-    // R (n x n): upper triangle of W with rows flipped to a non-negative diagonal; transpose != 0 writes R^T (lower)
-    const int i = blockIdx.y * blockDim.y + threadIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || j >= n) return;
-    double v = 0.0;
-    if (j >= i) {
-        v = W[(long)i * ld + j];
-        if (W[(long)i * ld + i] < 0.0) v = -v;
+// dst[j][i] = src[i][j], i < nr, j < nc (tile transpose through LDS)
+__global__ __launch_bounds__(256) void k_copy_t(double* __restrict__ dst, long ldd, const double* __restrict__ src,
+                                                long lds, int nr, int nc) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    for (int r = ty; r < 32; r += 8) {
+        const int i = i0 + r, j = j0 + tx;
+        tile[r][tx] = (i < nr && j < nc) ? src[(long)i * lds + j] : 0.0;
     }
-    if (transpose) R[(long)j * n + i] = v; else R[(long)i * n + j] = v;
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int j = j0 + r, i = i0 + tx;
+        if (i < nr && j < nc) dst[(long)j * ldd + i] = tile[tx][r];
+    }
+}
+
+// out[i][j] = sum_k C[k][i] H[j][k]  (= (H C)^T), i < nc_c, j < nr_h, k < kk: the top-left block of update_sqrt's
+// stacked matrix (base/sqrt.py:59-64).  One 32x32 tile per block on the MFMA.
+__global__ __launch_bounds__(256) void k_atbt(double* __restrict__ out, long ldo, const double* __restrict__ C, long ldc,
+                                              const double* __restrict__ H, long ldh, int nc_c, int nr_h, int kk) {
+    __shared__ double sC[32][33], sH[32][33];
+    const int t = threadIdx.x, w = t >> 6, lane = t & 63, fr = lane & 15, fk = lane >> 4, wr = w >> 1, wc = w & 1;
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    const int tx = t & 31, ty = t >> 5;
+    d4 acc = {0, 0, 0, 0};
+    for (int k0 = 0; k0 < kk; k0 += 32) {
+        for (int r = ty; r < 32; r += 8) {
+            const int k = k0 + r;
+            sC[r][tx] = (k < kk && i0 + tx < nc_c) ? C[(long)k * ldc + i0 + tx] : 0.0;   // sC[k][i]
+            const int j = j0 + r;
+            sH[r][tx] = (j < nr_h && k0 + tx < kk) ? H[(long)j * ldh + k0 + tx] : 0.0;   // sH[j][k]
+        }
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < 8; ++st)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sC[4 * st + fk][wr * 16 + fr], sH[wc * 16 + fr][4 * st + fk], acc, 0, 0, 0);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + wr * 16 + fk + 4 * r, j = j0 + wc * 16 + fr;
+        if (i < nc_c && j < nr_h) out[(long)i * ldo + j] = acc[r];
+    }
+}
+
+// Block [r0, r0+nr) x [c0, c0+nc) of the factorised work matrix -> out.  tri: entries below W's diagonal read as 0 (they
+// hold nothing of R); flip: rows whose diagonal entry is negative change sign (canonical factor); transpose: out is
+// (nc x nr) = block^T, else (nr x nc).
+__global__ void k_qr_block(const double* __restrict__ W, long ld, int r0, int c0, int nr, int nc,
+                           double* __restrict__ out, int transpose, int tri, int flip) {
+    const int i = blockIdx.y * blockDim.y + threadIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nr || j >= nc) return;
+    const long gi = r0 + i, gj = c0 + j;
+    double v = (tri && gj < gi) ? 0.0 : W[gi * ld + gj];
+    if (flip && W[gi * ld + gi] < 0.0) v = -v;
+    if (transpose) out[(long)j * nr + i] = v; else out[(long)i * nc + j] = v;
+}
+
+// X = R1^-1 R2 in place of R2: R1 = W[0:m, 0:m] upper triangular, R2 = W[0:m, c0:c0+nrhs] (base/sqrt.py:72 before the
+// transpose).  One block per 32 right-hand sides; block rows bottom-up: X_b = R_bb^-1 (R2_b - sum_{c>b} R_bc X_c), the
+// products on the MFMA, the 32x32 back substitution by one thread per right-hand side.  A zero pivot gives inf/nan like
+// `solve_triangular` does.
+__global__ __launch_bounds__(256) void k_trsm_upper(double* __restrict__ W, long ld, int m, int c0, int nrhs) {
+    __shared__ double sR[32][33], sX[32][33], sB[32][33];
+    const int t = threadIdx.x, w = t >> 6, lane = t & 63, fr = lane & 15, fk = lane >> 4, wr = w >> 1, wc = w & 1;
+    const int tx = t & 31, ty = t >> 5;
+    const int j0 = blockIdx.x * 32;                 // first right-hand side of this block
+    const int mb = (m + 31) / 32;
+    for (int b = mb - 1; b >= 0; --b) {
+        d4 acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = b * 32 + wr * 16 + fk + 4 * r, j = j0 + wc * 16 + fr;
+            acc[r] = (i < m && j < nrhs) ? W[(long)i * ld + c0 + j] : 0.0;
+        }
+        for (int c = b + 1; c < mb; ++c) {
+            for (int r = ty; r < 32; r += 8) {
+                const int i = b * 32 + r, k = c * 32 + tx;
+                sR[r][tx] = (i < m && k < m) ? W[(long)i * ld + k] : 0.0;                       // R_bc[i][k]
+                const int kx = c * 32 + r, j = j0 + tx;
+                sX[r][tx] = (kx < m && j < nrhs) ? W[(long)kx * ld + c0 + j] : 0.0;             // X_c[k][j]
+            }
+            __syncthreads();
+#pragma unroll
+            for (int st = 0; st < 8; ++st)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-sR[wr * 16 + fr][4 * st + fk], sX[4 * st + fk][wc * 16 + fr], acc, 0, 0, 0);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sB[wr * 16 + fk + 4 * r][wc * 16 + fr] = acc[r];
+        for (int r = ty; r < 32; r += 8) {
+            const int i = b * 32 + r, k = b * 32 + tx;
+            sR[r][tx] = (i < m && k < m) ? W[(long)i * ld + k] : (i == k ? 1.0 : 0.0);          // R_bb, identity beyond m
+        }
+        __syncthreads();
+        if (t < 32) {                                // right-hand side j0 + t: back substitution in registers
+            double x[32];
+#pragma unroll
+            for (int i = 31; i >= 0; --i) {
+                double v = sB[i][t];
+#pragma unroll
+                for (int k = i + 1; k < 32; ++k) v -= sR[i][k] * x[k];
+                x[i] = v / sR[i][i];
+            }
+#pragma unroll
+            for (int i = 0; i < 32; ++i)
+                if (b * 32 + i < m && j0 + t < nrhs) W[(long)(b * 32 + i) * ld + c0 + j0 + t] = x[i];
+        }
+        __syncthreads();
+    }
 }
 
 struct QrPlan {
@@ -324,9 +424,34 @@ int qr_inplace(pnmol_ctx* ctx, const QrPlan& pl) {
     return 0;
 }
 
+thread_local float g_last_qr_ms = -1.f;
+
+// qr_inplace bracketed by HIP events on the ctx stream (read back by pnmol_qr_last_ms after the caller's synchronise)
+struct QrTimer {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStream_t st;
+    explicit QrTimer(hipStream_t s) : st(s) {
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        hipEventRecord(e0, st);
+    }
+    void stop() { hipEventRecord(e1, st); }
+    ~QrTimer() {
+        if (hipEventSynchronize(e1) == hipSuccess) hipEventElapsedTime(&g_last_qr_ms, e0, e1);
+        hipEventDestroy(e0);
+        hipEventDestroy(e1);
+    }
+};
+
 }  // namespace
 
 extern "C" {
+
+int pnmol_qr_last_ms(float* ms) {
+    if (!ms) return -1;
+    *ms = g_last_qr_ms;
+    return 0;
+}
 
 int pnmol_qr_r(pnmol_ctx* ctx, const double* A, int rows, int cols, double* R) {
     if (!ctx || !A || !R || rows <= 0 || cols <= 0) return -1;
@@ -344,9 +469,14 @@ int pnmol_qr_r(pnmol_ctx* ctx, const double* A, int rows, int cols, double* R) {
         if (hipMemsetAsync(pl.W, 0, sizeof(double) * (size_t)pl.Mp * pl.ld, ctx->stream) != hipSuccess) { rc = -2; break; }
         if (hipMemcpy2DAsync(pl.W, sizeof(double) * pl.ld, A, sizeof(double) * cols, sizeof(double) * cols, rows,
                              hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = -2; break; }
-        if ((rc = qr_inplace(ctx, pl))) break;
-        hipLaunchKernelGGL(k_qr_extract, dim3((cols + 31) / 32, (cols + 7) / 8), dim3(32, 8), 0, ctx->stream, pl.W,
-                           (long)pl.ld, cols, dR, 0);
+        {
+            QrTimer tm(ctx->stream);
+            rc = qr_inplace(ctx, pl);
+            tm.stop();
+        }
+        if (rc) break;
+        hipLaunchKernelGGL(k_qr_block, dim3((cols + 31) / 32, (cols + 7) / 8), dim3(32, 8), 0, ctx->stream, pl.W,
+                           (long)pl.ld, 0, 0, cols, cols, dR, 0, 1, 1);
         if (hipMemcpyAsync(R, dR, sizeof(double) * (size_t)cols * cols, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { rc = -2; break; }
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = -2; break; }
     } while (0);
@@ -354,6 +484,118 @@ int pnmol_qr_r(pnmol_ctx* ctx, const double* A, int rows, int cols, double* R) {
     if (dR) hipFree(dR);
     qr_plan_free(&pl);
     return rc;
+}
+
+}  // extern "C"
+
+namespace {
+
+struct DevBuf {   // host matrix uploaded to the device for the duration of one call
+    double* p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    int upload(pnmol_ctx* ctx, const double* h, size_t count) {
+        if (hipMalloc(&p, sizeof(double) * count) != hipSuccess) return -4;
+        QCHECK(ctx, hipMemcpyAsync(p, h, sizeof(double) * count, hipMemcpyHostToDevice, ctx->stream));
+        return 0;
+    }
+    int alloc(size_t count) { return hipMalloc(&p, sizeof(double) * count) == hipSuccess ? 0 : -4; }
+};
+
+struct PlanGuard {
+    QrPlan pl;
+    ~PlanGuard() { qr_plan_free(&pl); }
+};
+
+inline dim3 tiles(int nc, int nr) { return dim3((nc + 31) / 32, (nr + 31) / 32); }
+
+int run_qr_timed(pnmol_ctx* ctx, const QrPlan& pl) {
+    QrTimer tm(ctx->stream);
+    const int rc = qr_inplace(ctx, pl);
+    tm.stop();
+    return rc;
+}
+
+// update_sqrt / update_sqrt_no_meascov (base/sqrt.py:33-95): E == nullptr is the noise-free variant
+int sqrt_update(pnmol_ctx* ctx, const double* H, int m, int D, const double* C, const double* E, double* C_new,
+                double* gain, double* Sl) {
+    if (!ctx || !H || !C || m <= 0 || D <= 0 || m > D) return -1;   // the reference pads E to (m, D): needs m <= D
+    QCHECK(ctx, hipSetDevice(ctx->device));
+    if (int rc = qr_configure(ctx)) return rc;
+    PlanGuard g;
+    if (int rc = qr_plan_alloc(ctx, D + m, m + D, &g.pl)) return rc == -2 ? -4 : rc;
+    const QrPlan& pl = g.pl;
+    DevBuf dH, dC, dE, dOut;
+    if (int rc = dH.upload(ctx, H, (size_t)m * D)) return rc;
+    if (int rc = dC.upload(ctx, C, (size_t)D * D)) return rc;
+    if (E) if (int rc = dE.upload(ctx, E, (size_t)m * m)) return rc;
+    if (int rc = dOut.alloc((size_t)D * D)) return rc;
+    QCHECK(ctx, hipMemsetAsync(pl.W, 0, sizeof(double) * (size_t)pl.Mp * pl.ld, ctx->stream));
+    // [[C^T H^T, C^T], [E^T, 0]]
+    hipLaunchKernelGGL(k_atbt, tiles(m, D), dim3(256), 0, ctx->stream, pl.W, (long)pl.ld, dC.p, (long)D, dH.p, (long)D, D, m, D);
+    hipLaunchKernelGGL(k_copy_t, tiles(D, D), dim3(256), 0, ctx->stream, pl.W + m, (long)pl.ld, dC.p, (long)D, D, D);
+    if (E)
+        hipLaunchKernelGGL(k_copy_t, tiles(m, m), dim3(256), 0, ctx->stream, pl.W + (long)D * pl.ld, (long)pl.ld, dE.p, (long)m, m, m);
+    if (int rc = run_qr_timed(ctx, pl)) return rc;
+    const dim3 tb(32, 8);
+    if (Sl) {   // R1^T
+        hipLaunchKernelGGL(k_qr_block, dim3((m + 31) / 32, (m + 7) / 8), tb, 0, ctx->stream, pl.W, (long)pl.ld, 0, 0, m, m, dOut.p, 1, 1, 1);
+        QCHECK(ctx, hipMemcpyAsync(Sl, dOut.p, sizeof(double) * (size_t)m * m, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (C_new) {   // R3^T
+        QCHECK(ctx, hipStreamSynchronize(ctx->stream));
+        hipLaunchKernelGGL(k_qr_block, dim3((D + 31) / 32, (D + 7) / 8), tb, 0, ctx->stream, pl.W, (long)pl.ld, m, m, D, D, dOut.p, 1, 1, 1);
+        QCHECK(ctx, hipMemcpyAsync(C_new, dOut.p, sizeof(double) * (size_t)D * D, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (gain) {   // (R1^-1 R2)^T
+        QCHECK(ctx, hipStreamSynchronize(ctx->stream));
+        hipLaunchKernelGGL(k_trsm_upper, dim3((D + 31) / 32), dim3(256), 0, ctx->stream, pl.W, (long)pl.ld, m, m, D);
+        hipLaunchKernelGGL(k_qr_block, dim3((D + 31) / 32, (m + 7) / 8), tb, 0, ctx->stream, pl.W, (long)pl.ld, 0, m, m, D, dOut.p, 1, 0, 0);
+        QCHECK(ctx, hipMemcpyAsync(gain, dOut.p, sizeof(double) * (size_t)D * m, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    QCHECK(ctx, hipGetLastError());
+    QCHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pnmol_sqrt_propagate_cholesky_factor(pnmol_ctx* ctx, const double* S1, int n, int k1, const double* S2, int k2,
+                                         double* chol_nn) {
+    if (!ctx || !S1 || !chol_nn || n <= 0 || k1 <= 0 || (S2 && k2 <= 0)) return -1;
+    if (!S2) k2 = 0;
+    QCHECK(ctx, hipSetDevice(ctx->device));
+    if (int rc = qr_configure(ctx)) return rc;
+    PlanGuard g;
+    if (int rc = qr_plan_alloc(ctx, k1 + k2, n, &g.pl)) return rc == -2 ? -4 : rc;
+    const QrPlan& pl = g.pl;
+    DevBuf d1, d2, dOut;
+    if (int rc = d1.upload(ctx, S1, (size_t)n * k1)) return rc;
+    if (S2) if (int rc = d2.upload(ctx, S2, (size_t)n * k2)) return rc;
+    if (int rc = dOut.alloc((size_t)n * n)) return rc;
+    QCHECK(ctx, hipMemsetAsync(pl.W, 0, sizeof(double) * (size_t)pl.Mp * pl.ld, ctx->stream));
+    // vstack(S1^T, S2^T), base/sqrt.py:11
+    hipLaunchKernelGGL(k_copy_t, tiles(k1, n), dim3(256), 0, ctx->stream, pl.W, (long)pl.ld, d1.p, (long)k1, n, k1);
+    if (S2)
+        hipLaunchKernelGGL(k_copy_t, tiles(k2, n), dim3(256), 0, ctx->stream, pl.W + (long)k1 * pl.ld, (long)pl.ld, d2.p, (long)k2, n, k2);
+    if (int rc = run_qr_timed(ctx, pl)) return rc;
+    hipLaunchKernelGGL(k_qr_block, dim3((n + 31) / 32, (n + 7) / 8), dim3(32, 8), 0, ctx->stream, pl.W, (long)pl.ld, 0, 0, n, n, dOut.p, 1, 1, 1);
+    QCHECK(ctx, hipMemcpyAsync(chol_nn, dOut.p, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost, ctx->stream));
+    QCHECK(ctx, hipGetLastError());
+    QCHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int pnmol_sqrt_update(pnmol_ctx* ctx, const double* H, int m, int D, const double* C, const double* meascov_sqrtm,
+                      double* C_new, double* gain, double* Sl) {
+    if (!meascov_sqrtm) return -1;
+    return sqrt_update(ctx, H, m, D, C, meascov_sqrtm, C_new, gain, Sl);
+}
+
+int pnmol_sqrt_update_no_meascov(pnmol_ctx* ctx, const double* H, int m, int D, const double* C, double* C_new,
+                                 double* gain, double* Sl) {
+    return sqrt_update(ctx, H, m, D, C, nullptr, C_new, gain, Sl);
 }
 
 }  // extern "C"

@@ -78,6 +78,13 @@ SYMBOLS = {
     "pnmol_filter_dims": (ctypes.c_int, [_vp] + [ctypes.POINTER(ctypes.c_int)] * 5),
     # include/pnmol_sqrt.h
     "pnmol_qr_r": (ctypes.c_int, [_vp, _c_double_p, ctypes.c_int, ctypes.c_int, _c_double_p]),
+    "pnmol_qr_last_ms": (ctypes.c_int, [ctypes.POINTER(ctypes.c_float)]),
+    "pnmol_sqrt_propagate_cholesky_factor": (ctypes.c_int, [_vp, _c_double_p, ctypes.c_int, ctypes.c_int, _c_double_p,
+                                                             ctypes.c_int, _c_double_p]),
+    "pnmol_sqrt_update": (ctypes.c_int, [_vp, _c_double_p, ctypes.c_int, ctypes.c_int, _c_double_p, _c_double_p,
+                                         _c_double_p, _c_double_p, _c_double_p]),
+    "pnmol_sqrt_update_no_meascov": (ctypes.c_int, [_vp, _c_double_p, ctypes.c_int, ctypes.c_int, _c_double_p,
+                                                    _c_double_p, _c_double_p, _c_double_p]),
 }
 
 _lib = None
@@ -147,6 +154,41 @@ class Context:
         R = np.empty((cols, cols))
         self.check(self.lib.pnmol_qr_r(self.handle, _dp(A), rows, cols, _dp(R)), "pnmol_qr_r")
         return R
+
+    def sqrt_propagate(self, S1, S2=None):
+        S1 = _f64(S1)
+        n, k1 = S1.shape
+        out = np.empty((n, n))
+        if S2 is None:
+            rc = self.lib.pnmol_sqrt_propagate_cholesky_factor(self.handle, _dp(S1), n, k1, None, 0, _dp(out))
+        else:
+            S2 = _f64(S2)
+            if S2.shape[0] != n:
+                raise ValueError(f"S1 {S1.shape} and S2 {S2.shape} must have the same number of rows")
+            rc = self.lib.pnmol_sqrt_propagate_cholesky_factor(self.handle, _dp(S1), n, k1, _dp(S2), S2.shape[1], _dp(out))
+        self.check(rc, "pnmol_sqrt_propagate_cholesky_factor")
+        return out
+
+    def sqrt_update(self, H, C, meascov_sqrtm=None):
+        H, C = _f64(H), _f64(C)
+        m, D = H.shape
+        if C.shape != (D, D):
+            raise ValueError(f"cov_cholesky must be {(D, D)}, got {C.shape}")
+        if m > D:
+            raise ValueError("update_sqrt needs output_dim <= input_dim (base/sqrt.py:56-58)")
+        C_new, gain, Sl = np.empty((D, D)), np.empty((D, m)), np.empty((m, m))
+        if meascov_sqrtm is None:
+            rc = self.lib.pnmol_sqrt_update_no_meascov(self.handle, _dp(H), m, D, _dp(C), _dp(C_new), _dp(gain), _dp(Sl))
+        else:
+            E = _f64(meascov_sqrtm, (m, m))
+            rc = self.lib.pnmol_sqrt_update(self.handle, _dp(H), m, D, _dp(C), _dp(E), _dp(C_new), _dp(gain), _dp(Sl))
+        self.check(rc, "pnmol_sqrt_update")
+        return C_new, gain, Sl
+
+    def qr_last_ms(self):
+        ms = ctypes.c_float(0)
+        self.lib.pnmol_qr_last_ms(ctypes.byref(ms))
+        return ms.value
 
     def check(self, rc, what):
         if rc != 0:

@@ -1,3 +1,3 @@
 """Auxiliary pieces: IWP prior, random variables (reference: src/pnmol/base/)."""
 
-from . import iwp, rv, stacked_ssm  # noqa: F401
+from . import iwp, rv, sqrt, stacked_ssm  # noqa: F401
