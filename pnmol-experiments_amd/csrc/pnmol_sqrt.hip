@@ -45,11 +45,13 @@ constexpr int VLD = 33;           // LDS row stride of V in k_qr_apply (bank-con
     } while (0)
 
 struct FactorLds {
-    double A[CR * QB];      // the chunk's panel columns, stacked; becomes V (unit lower trapezoidal)
+    double A[CR * QB];      // V (unit lower trapezoidal), for the Gram product and the workspace copy
     double R[QB * QB];      // rows of R as they are finished
     double red[FAN * QB];   // per-wave partial inner products
     double G[QB * QB];      // V^T V
     double tau[QB], scale[QB];
+    double col[2][CR];      // column J of the working matrix (ping-pong by step parity)
+    double rowb[2][QB];     // row J
 };
 
 // Member q of chunk c at tree level s of panel p.
@@ -69,22 +71,32 @@ __global__ __launch_bounds__(FT) void k_qr_factor(double* __restrict__ W, long l
     if (nm == 0 || (nm == 1 && s > 1)) return;  // a lone survivor is already triangular (k_qr_apply skips it too)
     const int rows = nm * QB;
 
+    // the thread's 16 entries of column k stay in registers; what the others need of the current step -- column J and
+    // row J -- goes through the double-buffered L.col / L.rowb, published at the end of the step before
+    double a[RPT];
+#pragma unroll
     for (int r = 0; r < RPT; ++r) {
         const int i = g + NG * r;
         const int q = i >> 5;
-        double v = 0.0;
-        if (q < nm) v = W[((long)member_rb(p, s, c, q) * QB + (i & 31)) * ld + (long)p * QB + k];
-        L.A[i * QB + k] = v;
+        a[r] = (q < nm) ? W[((long)member_rb(p, s, c, q) * QB + (i & 31)) * ld + (long)p * QB + k] : 0.0;
     }
+    if (k == 0) {
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) L.col[0][g + NG * r] = a[r];
+    }
+    if (g == 0) L.rowb[0][k] = a[0];
     __syncthreads();
 
+#pragma unroll
     for (int J = 0; J < QB; ++J) {
+        const int cur = J & 1;
+        double vi[RPT];
         double part = 0.0;
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
             const int i = g + NG * r;
-            const double a = (i > J && i < rows) ? L.A[i * QB + J] : 0.0;
-            part += a * L.A[i * QB + k];
+            vi[r] = (i > J && i < rows) ? L.col[cur][i] : 0.0;
+            part += vi[r] * a[r];
         }
         part += __shfl_xor(part, 32);  // the wave's two row groups
         if (lane < 32) L.red[w * QB + k] = part;
@@ -96,17 +108,16 @@ __global__ __launch_bounds__(FT) void k_qr_factor(double* __restrict__ W, long l
             sJ += L.red[ww * QB + J];
         }
         // dlarfg: H = I - tau v v^T, v = [1; x / (alpha - beta)], beta = -sign(alpha) |(alpha, x)|
-        const double alpha = L.A[J * QB + J];
+        const double alpha = L.rowb[cur][J], aJk = L.rowb[cur][k];
         double beta = alpha, tau = 0.0, scale = 0.0;
         if (sJ != 0.0) {
             beta = -copysign(sqrt(alpha * alpha + sJ), alpha);
             tau = (beta - alpha) / beta;
             scale = 1.0 / (alpha - beta);
         }
-        const double wk = L.A[J * QB + k] + sk * scale;  // v^T A[:, k]
-        const double f = tau * wk;
+        const double f = tau * (aJk + sk * scale);  // tau v^T A[:, k]
         if (g == 0) {
-            L.R[J * QB + k] = (k > J) ? L.A[J * QB + k] - f : (k == J ? beta : 0.0);
+            L.R[J * QB + k] = (k > J) ? aJk - f : (k == J ? beta : 0.0);
             if (k == J) {
                 L.tau[J] = tau;
                 L.scale[J] = scale;
@@ -115,22 +126,25 @@ __global__ __launch_bounds__(FT) void k_qr_factor(double* __restrict__ W, long l
         if (k > J) {
             const double fs = f * scale;
 #pragma unroll
-            for (int r = 0; r < RPT; ++r) {
-                const int i = g + NG * r;
-                if (i > J && i < rows) L.A[i * QB + k] -= fs * L.A[i * QB + J];
+            for (int r = 0; r < RPT; ++r) a[r] -= fs * vi[r];   // vi = 0 outside the reflector's rows
+        }
+        if (J + 1 < QB) {
+            if (k == J + 1) {
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) L.col[cur ^ 1][g + NG * r] = a[r];
             }
+            if (g == (J + 1) % NG) L.rowb[cur ^ 1][k] = a[(J + 1) / NG];
         }
         __syncthreads();
     }
 
-    // V: unit lower trapezoidal
+    // V: unit lower trapezoidal (column k of the reflectors is rows i > k of the registers, unscaled so far)
     {
         const double sc = L.scale[k];
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
             const int i = g + NG * r;
-            const double a = L.A[i * QB + k];
-            L.A[i * QB + k] = (i > k && i < rows) ? a * sc : (i == k ? 1.0 : 0.0);
+            L.A[i * QB + k] = (i > k && i < rows) ? a[r] * sc : (i == k ? 1.0 : 0.0);
         }
     }
     __syncthreads();
@@ -596,6 +610,542 @@ int pnmol_sqrt_update(pnmol_ctx* ctx, const double* H, int m, int D, const doubl
 int pnmol_sqrt_update_no_meascov(pnmol_ctx* ctx, const double* H, int m, int D, const double* C, double* C_new,
                                  double* gain, double* Sl) {
     return sqrt_update(ctx, H, m, D, C, nullptr, C_new, gain, Sl);
+}
+
+}  // extern "C"
+
+// ==========================================================================================================
+// The filter step in square-root form, as the reference writes it (white.py:96-146): the state is (mean, cov_sqrtm),
+// the predict is one QR of [(A Pinv Cl)^T; Ql^T] (2D x D), the update one QR of [[R H^T, R], [E^T, 0]] ((D+m) x (m+D)).
+// Everything in the reference's F-flattened state order (index j*n + a = derivative a at mesh point j), dense H.
+// ==========================================================================================================
+namespace {
+
+constexpr int SQN = 4;   // n = nu + 1 <= 4
+
+struct SqConst {
+    double A1[SQN * SQN];   // base/iwp.py:17  flip(pascal lower)
+    double p[SQN], pinv[SQN];   // Nordsieck scales of this step (base/iwp.py:55-62)
+    int n;
+};
+
+// T1 = A Pinv Cl, A = I (x) A1 (white.py:101-103): thread (point j, column c) does the n rows of point j
+__global__ void k_sq_rows(double* __restrict__ T1, const double* __restrict__ Cl, int d, int D, SqConst k) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+    if (c >= D || j >= d) return;
+    double v[SQN];
+    for (int b = 0; b < k.n; ++b) v[b] = k.pinv[b] * Cl[(long)(j * k.n + b) * D + c];
+    for (int a = 0; a < k.n; ++a) {
+        double s = 0.0;
+        for (int b = 0; b < k.n; ++b) s += k.A1[a * SQN + b] * v[b];
+        T1[(long)(j * k.n + a) * D + c] = s;
+    }
+}
+
+__global__ void k_sq_mean(double* __restrict__ mp, const double* __restrict__ mean, int d, SqConst k) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= d) return;
+    for (int a = 0; a < k.n; ++a) {
+        double s = 0.0;
+        for (int b = 0; b < k.n; ++b) s += k.A1[a * SQN + b] * k.pinv[b] * mean[j * k.n + b];
+        mp[j * k.n + a] = s;
+    }
+}
+
+// out[i][j] = sum_{k >= i} R[i][k] Hraw[j][k] p[k % n]  (= (H Cl-)^T with Cl- = R^T, H = Hraw P): 32x32 tile per block
+__global__ __launch_bounds__(256) void k_rht(double* __restrict__ out, long ldo, const double* __restrict__ R, long ldr,
+                                             const double* __restrict__ Hraw, int D, int m, SqConst kc) {
+    __shared__ double sA[32][33], sH[32][33];
+    const int t = threadIdx.x, w = t >> 6, lane = t & 63, fr = lane & 15, fk = lane >> 4, wr = w >> 1, wc = w & 1;
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32, tx = t & 31, ty = t >> 5;
+    d4 acc = {0, 0, 0, 0};
+    for (int k0 = i0; k0 < D; k0 += 32) {
+        const int k = k0 + tx;
+        const double pk = kc.p[k % kc.n];
+        for (int r = ty; r < 32; r += 8) {
+            const int i = i0 + r, j = j0 + r;
+            sA[r][tx] = (i < D && k < D && k >= i) ? R[(long)i * ldr + k] : 0.0;
+            sH[r][tx] = (j < m && k < D) ? Hraw[(long)j * D + k] * pk : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < 8; ++st)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[wr * 16 + fr][4 * st + fk], sH[wc * 16 + fr][4 * st + fk], acc, 0, 0, 0);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + wr * 16 + fk + 4 * r, j = j0 + wc * 16 + fr;
+        if (i < D && j < m) out[(long)i * ldo + j] = acc[r];
+    }
+}
+
+// W2[i][c0 + k] = R[i][k] (upper triangle, zero below)
+__global__ void k_sq_fill_r(double* __restrict__ W2, long ld2, int c0, const double* __restrict__ R, long ldr, int D) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y * blockDim.y + threadIdx.y;
+    if (k >= D || i >= D) return;
+    W2[(long)i * ld2 + c0 + k] = (k >= i) ? R[(long)i * ldr + k] : 0.0;
+}
+
+// z = Hraw P mp + shift (white.py:169-186): one wave per row
+__global__ __launch_bounds__(256) void k_sq_gemv_z(double* __restrict__ z, const double* __restrict__ Hraw,
+                                                   const double* __restrict__ mp, const double* __restrict__ shift,
+                                                   int m, int D, SqConst kc) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= m) return;
+    double s = 0.0;
+    for (int k = lane; k < D; k += 64) s += Hraw[(long)j * D + k] * kc.p[k % kc.n] * mp[k];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) z[j] = s + shift[j];
+}
+
+// y = R1^-T z and x = R1c^-1 z (R1c = R1 with rows flipped to a positive diagonal; white.py:125 solves with Sl^T = R1),
+// R1 = W[0:m, 0:m] upper.  norms = {|y|^2, |x|^2}.  One block; 32-wide diagonal solves by one wave in registers.
+__global__ __launch_bounds__(1024) void k_sq_trsv(const double* __restrict__ W, long ld, int m,
+                                                  const double* __restrict__ z, double* __restrict__ y,
+                                                  double* __restrict__ x, double* __restrict__ norms) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char qr_lds_raw[];
+    const int mb = (m + 31) / 32, mp = mb * 32;
+    double* sv = reinterpret_cast<double*>(qr_lds_raw);   // running right-hand side
+    double* ss = sv + mp;                                  // solution
+    double* tile = ss + mp;                                // 32 x 33
+    double* red = tile + 32 * 33;                          // 32
+    const int t = threadIdx.x, lane = t & 63;
+    // ---- forward: (R1^T) y = z, right-looking
+    for (int i = t; i < mp; i += 1024) sv[i] = i < m ? z[i] : 0.0;
+    for (int b = 0; b < mb; ++b) {
+        __syncthreads();
+        {
+            const int r = t >> 5, c = t & 31, gi = b * 32 + r, gj = b * 32 + c;
+            tile[r * 33 + c] = (gi < m && gj < m) ? W[(long)gi * ld + gj] : (gi == gj ? 1.0 : 0.0);
+        }
+        __syncthreads();
+        if (t < 64) {
+            const int i = lane & 31;
+            double v = sv[b * 32 + i];
+            for (int k = 0; k < 32; ++k) {
+                const double yk = __shfl(v, k) / tile[k * 33 + k];
+                if (i > k) v -= tile[k * 33 + i] * yk;
+                if (i == k) v = yk;
+            }
+            if (lane < 32) ss[b * 32 + i] = v;
+        }
+        __syncthreads();
+        for (int i = (b + 1) * 32 + t; i < m; i += 1024) {
+            double a = 0.0;
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) {
+                const int gk = b * 32 + k;
+                if (gk < m) a += W[(long)gk * ld + i] * ss[gk];
+            }
+            sv[i] -= a;
+        }
+    }
+    __syncthreads();
+    double ny = 0.0;
+    for (int i = t; i < m; i += 1024) {
+        y[i] = ss[i];
+        ny += ss[i] * ss[i];
+    }
+    __syncthreads();
+    // ---- backward: R1 x = S z, left-looking (row dot products)
+    for (int b = mb - 1; b >= 0; --b) {
+        const int r = t >> 5, l32 = t & 31, gi = b * 32 + r;
+        double a = 0.0;
+        if (gi < m)
+            for (int k = (b + 1) * 32 + l32; k < m; k += 32) a += W[(long)gi * ld + k] * ss[k];
+        for (int o = 16; o > 0; o >>= 1) a += __shfl_xor(a, o);
+        if (l32 == 0) {
+            double rhs = 0.0;
+            if (gi < m) rhs = (W[(long)gi * ld + gi] < 0.0 ? -z[gi] : z[gi]) - a;
+            red[r] = rhs;
+        }
+        {
+            const int c = t & 31, gj = b * 32 + c;
+            tile[r * 33 + c] = (gi < m && gj < m) ? W[(long)gi * ld + gj] : (gi == gj ? 1.0 : 0.0);
+        }
+        __syncthreads();
+        if (t < 64) {
+            const int i = lane & 31;
+            double v = red[i];
+            for (int k = 31; k >= 0; --k) {
+                const double xk = __shfl(v, k) / tile[k * 33 + k];
+                if (i < k) v -= tile[i * 33 + k] * xk;
+                if (i == k) v = xk;
+            }
+            if (lane < 32) ss[b * 32 + i] = v;
+        }
+        __syncthreads();
+    }
+    double nx = 0.0;
+    for (int i = t; i < m; i += 1024) {
+        x[i] = ss[i];
+        nx += ss[i] * ss[i];
+    }
+    // block reduction of the two norms
+    for (int o = 32; o > 0; o >>= 1) {
+        ny += __shfl_xor(ny, o);
+        nx += __shfl_xor(nx, o);
+    }
+    __syncthreads();
+    if (lane == 0) {
+        tile[t >> 6] = ny;
+        tile[64 + (t >> 6)] = nx;
+    }
+    __syncthreads();
+    if (t == 0) {
+        double a = 0.0, c = 0.0;
+        for (int q = 0; q < 16; ++q) {
+            a += tile[q];
+            c += tile[64 + q];
+        }
+        norms[0] = a;
+        norms[1] = c;
+    }
+}
+
+// mean[c] = p[c % n] (mp[c] - sum_i R2[i][c] y[i]),  R2 = W2[0:m, c0:c0+D]  (m_new = mp - K z, K z = R2^T R1^-T z)
+__global__ __launch_bounds__(256) void k_sq_mean_update(double* __restrict__ mean, const double* __restrict__ mp,
+                                                        const double* __restrict__ W2, long ld2, int c0,
+                                                        const double* __restrict__ y, int m, int D, SqConst kc) {
+    __shared__ double part[4][64];
+    const int tx = threadIdx.x & 63, g = threadIdx.x >> 6, c = blockIdx.x * 64 + tx;
+    double s = 0.0;
+    if (c < D)
+        for (int i = g; i < m; i += 4) s += W2[(long)i * ld2 + c0 + c] * y[i];
+    part[g][tx] = s;
+    __syncthreads();
+    if (g == 0 && c < D) mean[c] = kc.p[c % kc.n] * (mp[c] - (part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]));
+}
+
+// Cl[r][c] = p[r % n] s_c R3[c][r] for c <= r, 0 above: the new factor P R3^T with a non-negative diagonal
+// (R3 = W2[c0 + c][c0 + r]); tile transpose through LDS
+__global__ __launch_bounds__(256) void k_sq_state_out(double* __restrict__ Cl, int D, const double* __restrict__ W2,
+                                                      long ld2, int c0, SqConst kc) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int cb = blockIdx.x * 32, rb = blockIdx.y * 32;   // tile of Cl: rows rb.., cols cb..
+    for (int q = ty; q < 32; q += 8) {
+        const int c = cb + q, r = rb + tx;                   // read R3[c][r], contiguous in r
+        double v = 0.0;
+        if (c < D && r < D && c <= r) {
+            v = W2[(long)(c0 + c) * ld2 + c0 + r];
+            if (W2[(long)(c0 + c) * ld2 + c0 + c] < 0.0) v = -v;
+        }
+        tile[q][tx] = v;
+    }
+    __syncthreads();
+    for (int q = ty; q < 32; q += 8) {
+        const int r = rb + q, c = cb + tx;
+        if (r < D && c < D) Cl[(long)r * D + c] = kc.p[r % kc.n] * tile[tx][q];
+    }
+}
+
+// per-step read-out (figure1.py:76-80): mean of derivative 0 and sqrt(diag(Cl Cl^T)) at it; one wave per mesh point
+__global__ __launch_bounds__(256) void k_sq_readout(double* __restrict__ means, double* __restrict__ stds,
+                                                    const double* __restrict__ mean, const double* __restrict__ Cl,
+                                                    int d, int n, int D) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= d) return;
+    double s = 0.0;
+    const double* row = Cl + (long)(j * n) * D;
+    for (int c = lane; c < D; c += 64) s += row[c] * row[c];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) {
+        means[j] = mean[j * n];
+        stds[j] = sqrt(s);
+    }
+}
+
+}  // namespace
+
+struct pnmol_sqrt_filter {
+    pnmol_ctx* ctx = nullptr;
+    int d = 0, n = 0, nu = 0, nB = 0, m = 0, D = 0;
+    double A1[SQN * SQN] = {0};
+    double *Hraw = nullptr, *shift = nullptr, *EtT = nullptr, *QlT = nullptr;
+    double *mean = nullptr, *Cl = nullptr, *T1 = nullptr, *mp = nullptr, *z = nullptr, *y = nullptr, *x = nullptr,
+           *norms = nullptr;
+    double t = 0.0;
+    QrPlan q1, q2;
+    std::vector<double> hB;     // boundary rows, kept for set_operator
+    float last_ms = -1.f;
+};
+
+namespace {
+
+double sq_nordsieck(int nu, int a, double dt) {   // base/iwp.py:55-62
+    double fact = 1.0;
+    for (int q = 2; q <= nu - a; ++q) fact *= q;
+    return std::pow(std::fabs(dt), nu - a + 0.5) / fact;
+}
+
+SqConst sq_const(const pnmol_sqrt_filter* f, double dt) {
+    SqConst k;
+    std::memset(&k, 0, sizeof(k));
+    std::memcpy(k.A1, f->A1, sizeof(k.A1));
+    k.n = f->n;
+    for (int a = 0; a < f->n; ++a) {
+        k.p[a] = sq_nordsieck(f->nu, a, dt);
+        k.pinv[a] = 1.0 / k.p[a];
+    }
+    return k;
+}
+
+// Hraw = [E1 - M E0; B E0] (white.py:169-186 with E0 P, E1 P factored into the per-step column scaling) and shift
+int sq_upload_operator(pnmol_sqrt_filter* f, const double* M, const double* shift_d) {
+    const int d = f->d, n = f->n, m = f->m, D = f->D, nB = f->nB;
+    std::vector<double> H((size_t)m * D, 0.0), sh(m, 0.0);
+    for (int i = 0; i < d; ++i) {
+        for (int j = 0; j < d; ++j) H[(size_t)i * D + (size_t)j * n] = -M[(size_t)i * d + j];
+        H[(size_t)i * D + (size_t)i * n + 1] += 1.0;
+        if (shift_d) sh[i] = shift_d[i];
+    }
+    for (int i = 0; i < nB; ++i)
+        for (int j = 0; j < d; ++j) H[(size_t)(d + i) * D + (size_t)j * n] = f->hB[(size_t)i * d + j];
+    pnmol_ctx* ctx = f->ctx;
+    QCHECK(ctx, hipMemcpyAsync(f->Hraw, H.data(), sizeof(double) * H.size(), hipMemcpyHostToDevice, ctx->stream));
+    QCHECK(ctx, hipMemcpyAsync(f->shift, sh.data(), sizeof(double) * m, hipMemcpyHostToDevice, ctx->stream));
+    QCHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int sq_step(pnmol_sqrt_filter* f, double dt, double* norms_out) {
+    pnmol_ctx* ctx = f->ctx;
+    hipStream_t st = ctx->stream;
+    const int d = f->d, n = f->n, m = f->m, D = f->D;
+    const SqConst kc = sq_const(f, dt);
+    const QrPlan &q1 = f->q1, &q2 = f->q2;
+    // predict (white.py:101-103, :114): mp = A Pinv m, Cl- = R^T of [(A Pinv Cl)^T; Ql^T]
+    hipLaunchKernelGGL(k_sq_mean, dim3((d + 255) / 256), dim3(256), 0, st, f->mp, f->mean, d, kc);
+    hipLaunchKernelGGL(k_sq_rows, dim3((D + 255) / 256, d), dim3(256), 0, st, f->T1, f->Cl, d, D, kc);
+    QCHECK(ctx, hipMemsetAsync(q1.W, 0, sizeof(double) * (size_t)q1.Mp * q1.ld, st));
+    hipLaunchKernelGGL(k_copy_t, tiles(D, D), dim3(256), 0, st, q1.W, (long)q1.ld, f->T1, (long)D, D, D);
+    QCHECK(ctx, hipMemcpy2DAsync(q1.W + (long)D * q1.ld, sizeof(double) * q1.ld, f->QlT, sizeof(double) * D,
+                                 sizeof(double) * D, D, hipMemcpyDeviceToDevice, st));
+    if (int rc = qr_inplace(ctx, q1)) return rc;
+    // update (white.py:104, :120-123): QR of [[R H^T, R], [E^T, 0]]
+    QCHECK(ctx, hipMemsetAsync(q2.W, 0, sizeof(double) * (size_t)q2.Mp * q2.ld, st));
+    hipLaunchKernelGGL(k_rht, tiles(m, D), dim3(256), 0, st, q2.W, (long)q2.ld, q1.W, (long)q1.ld, f->Hraw, D, m, kc);
+    hipLaunchKernelGGL(k_sq_fill_r, dim3((D + 31) / 32, (D + 7) / 8), dim3(32, 8), 0, st, q2.W, (long)q2.ld, m, q1.W,
+                       (long)q1.ld, D);
+    QCHECK(ctx, hipMemcpy2DAsync(q2.W + (long)D * q2.ld, sizeof(double) * q2.ld, f->EtT, sizeof(double) * m,
+                                 sizeof(double) * m, m, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_sq_gemv_z, dim3((m + 3) / 4), dim3(256), 0, st, f->z, f->Hraw, f->mp, f->shift, m, D, kc);
+    if (int rc = qr_inplace(ctx, q2)) return rc;
+    const int mpad = (m + 31) / 32 * 32;
+    const size_t trsv_lds = sizeof(double) * (2 * (size_t)mpad + 32 * 33 + 32 + 128);
+    hipLaunchKernelGGL(k_sq_trsv, dim3(1), dim3(1024), trsv_lds, st, q2.W, (long)q2.ld, m, f->z, f->y, f->x, norms_out);
+    hipLaunchKernelGGL(k_sq_mean_update, dim3((D + 63) / 64), dim3(256), 0, st, f->mean, f->mp, q2.W, (long)q2.ld, m,
+                       f->y, m, D, kc);
+    hipLaunchKernelGGL(k_sq_state_out, tiles(D, D), dim3(256), 0, st, f->Cl, D, q2.W, (long)q2.ld, m, kc);
+    QCHECK(ctx, hipGetLastError());
+    f->t += dt;
+    return 0;
+}
+
+void sq_fill_out(pnmol_step_out* o, double t, const double* norms, int m) {
+    o->t_new = t;
+    o->sigma2_whitened = norms[0] / m;
+    o->diffusion_squared_local = norms[1] / m;
+    o->error_sigma2 = std::nan("");
+    o->info = (std::isfinite(norms[0]) && std::isfinite(norms[1])) ? -1 : 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pnmol_sqrt_filter_destroy(pnmol_sqrt_filter* f) {
+    if (!f) return -1;
+    hipSetDevice(f->ctx->device);
+    for (double* p : {f->Hraw, f->shift, f->EtT, f->QlT, f->mean, f->Cl, f->T1, f->mp, f->z, f->y, f->x, f->norms})
+        if (p) hipFree(p);
+    qr_plan_free(&f->q1);
+    qr_plan_free(&f->q2);
+    delete f;
+    return 0;
+}
+
+int pnmol_sqrt_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_sqrt_filter** out) {
+    if (!ctx || !desc || !out) return -1;
+    *out = nullptr;
+    const int d = desc->d, nu = desc->num_derivatives, n = nu + 1, nB = desc->nB;
+    if (d <= 0 || nu < 1 || n > SQN || nB < 0 || !desc->L || !desc->E_sqrtm || !desc->Gamma || (nB > 0 && (!desc->B || !desc->R_sqrtm))) {
+        ctx->err = "pnmol_sqrt_filter_create: bad descriptor";
+        return -1;
+    }
+    if (desc->d_state != 0 && desc->d_state != d) {
+        ctx->err = "pnmol_sqrt_filter_create: the square-root form is built for the white-noise model (d_state = d)";
+        return -1;
+    }
+    QCHECK(ctx, hipSetDevice(ctx->device));
+    if (int rc = qr_configure(ctx)) return rc;
+    const int m = d + nB, D = n * d;
+    if (sizeof(double) * (2 * (size_t)((m + 31) / 32 * 32) + 32 * 33 + 160) > 160 * 1024) {
+        ctx->err = "pnmol_sqrt_filter_create: m too large for the single-block triangular solve";
+        return -1;
+    }
+    pnmol_sqrt_filter* f = new pnmol_sqrt_filter();
+    f->ctx = ctx, f->d = d, f->n = n, f->nu = nu, f->nB = nB, f->m = m, f->D = D;
+    if (nB) f->hB.assign(desc->B, desc->B + (size_t)nB * d);
+    double Q1[SQN * SQN] = {0}, Lq[SQN * SQN] = {0};
+    for (int a = 0; a < n; ++a)
+        for (int b = 0; b < n; ++b) {   // base/iwp.py:13-30: flip both axes of pascal (lower) and hilbert
+            const int ia = n - 1 - a, ib = n - 1 - b;
+            double binom = 0.0;
+            if (ib <= ia) {
+                binom = 1.0;
+                for (int q = 1; q <= ib; ++q) binom = binom * (ia - ib + q) / q;
+            }
+            f->A1[a * SQN + b] = binom;
+            Q1[a * SQN + b] = 1.0 / (ia + ib + 1.0);
+        }
+    for (int j = 0; j < n; ++j)      // Lq = chol(Q1), n <= 4
+        for (int i = j; i < n; ++i) {
+            double s = Q1[i * SQN + j];
+            for (int k = 0; k < j; ++k) s -= Lq[i * SQN + k] * Lq[j * SQN + k];
+            Lq[i * SQN + j] = (i == j) ? std::sqrt(s) : s / Lq[j * SQN + j];
+        }
+    int rc = 0;
+    do {
+        auto alloc = [&](double** p, size_t count) { return hipMalloc(p, sizeof(double) * count) == hipSuccess; };
+        if (!alloc(&f->Hraw, (size_t)m * D) || !alloc(&f->shift, m) || !alloc(&f->EtT, (size_t)m * m) ||
+            !alloc(&f->QlT, (size_t)D * D) || !alloc(&f->mean, D) || !alloc(&f->Cl, (size_t)D * D) ||
+            !alloc(&f->T1, (size_t)D * D) || !alloc(&f->mp, D) || !alloc(&f->z, m) || !alloc(&f->y, m) ||
+            !alloc(&f->x, m) || !alloc(&f->norms, 2)) { rc = -4; break; }
+        if ((rc = qr_plan_alloc(ctx, 2 * D, D, &f->q1))) { rc = -4; break; }
+        if ((rc = qr_plan_alloc(ctx, D + m, m + D, &f->q2))) { rc = -4; break; }
+        // Ql^T = (Gamma (x) Lq)^T (base/iwp.py:32-53), E^T = blockdiag(E_sqrtm, R_sqrtm)^T (white.py:184)
+        std::vector<double> QlT((size_t)D * D, 0.0), EtT((size_t)m * m, 0.0);
+        for (int j = 0; j < d; ++j)
+            for (int j2 = 0; j2 <= j; ++j2) {
+                const double gjj = desc->Gamma[(size_t)j * d + j2];
+                if (gjj == 0.0) continue;
+                for (int a = 0; a < n; ++a)
+                    for (int b = 0; b <= a; ++b)
+                        QlT[(size_t)(j2 * n + b) * D + (size_t)(j * n + a)] = gjj * Lq[a * SQN + b];
+            }
+        for (int i = 0; i < d; ++i)
+            for (int j = 0; j < d; ++j) EtT[(size_t)j * m + i] = desc->E_sqrtm[(size_t)i * d + j];
+        for (int i = 0; i < nB; ++i)
+            for (int j = 0; j < nB; ++j) EtT[(size_t)(d + j) * m + d + i] = desc->R_sqrtm[(size_t)i * nB + j];
+        if (hipMemcpy(f->QlT, QlT.data(), sizeof(double) * QlT.size(), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(f->EtT, EtT.data(), sizeof(double) * EtT.size(), hipMemcpyHostToDevice) != hipSuccess) { rc = -2; break; }
+        if ((rc = sq_upload_operator(f, desc->L, nullptr))) break;
+    } while (0);
+    if (rc) {
+        if (rc == -2 && ctx->err.empty()) ctx->err = hipGetErrorString(hipGetLastError());
+        pnmol_sqrt_filter_destroy(f);
+        return rc;
+    }
+    *out = f;
+    return 0;
+}
+
+int pnmol_sqrt_filter_set_operator(pnmol_sqrt_filter* f, const double* M_dd, const double* shift_d) {
+    if (!f || !M_dd) return -1;
+    QCHECK(f->ctx, hipSetDevice(f->ctx->device));
+    return sq_upload_operator(f, M_dd, shift_d);
+}
+
+int pnmol_sqrt_filter_set_state(pnmol_sqrt_filter* f, double t, const double* mean_nd, const double* cov_sqrtm_DD) {
+    if (!f || !mean_nd || !cov_sqrtm_DD) return -1;
+    pnmol_ctx* ctx = f->ctx;
+    QCHECK(ctx, hipSetDevice(ctx->device));
+    std::vector<double> mv(f->D);
+    for (int a = 0; a < f->n; ++a)
+        for (int j = 0; j < f->d; ++j) mv[(size_t)j * f->n + a] = mean_nd[(size_t)a * f->d + j];   // reshape(-1, order="F")
+    QCHECK(ctx, hipMemcpyAsync(f->mean, mv.data(), sizeof(double) * f->D, hipMemcpyHostToDevice, ctx->stream));
+    QCHECK(ctx, hipMemcpyAsync(f->Cl, cov_sqrtm_DD, sizeof(double) * (size_t)f->D * f->D, hipMemcpyHostToDevice, ctx->stream));
+    QCHECK(ctx, hipStreamSynchronize(ctx->stream));
+    f->t = t;
+    return 0;
+}
+
+int pnmol_sqrt_filter_get_state(pnmol_sqrt_filter* f, double* t, double* mean_nd, double* cov_sqrtm_DD) {
+    if (!f) return -1;
+    pnmol_ctx* ctx = f->ctx;
+    QCHECK(ctx, hipSetDevice(ctx->device));
+    if (t) *t = f->t;
+    if (mean_nd) {
+        std::vector<double> mv(f->D);
+        QCHECK(ctx, hipMemcpyAsync(mv.data(), f->mean, sizeof(double) * f->D, hipMemcpyDeviceToHost, ctx->stream));
+        QCHECK(ctx, hipStreamSynchronize(ctx->stream));
+        for (int a = 0; a < f->n; ++a)
+            for (int j = 0; j < f->d; ++j) mean_nd[(size_t)a * f->d + j] = mv[(size_t)j * f->n + a];
+    }
+    if (cov_sqrtm_DD) {
+        QCHECK(ctx, hipMemcpyAsync(cov_sqrtm_DD, f->Cl, sizeof(double) * (size_t)f->D * f->D, hipMemcpyDeviceToHost, ctx->stream));
+        QCHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return 0;
+}
+
+int pnmol_sqrt_filter_predict_mean(pnmol_sqrt_filter* f, double dt, double* m_at_d) {
+    if (!f || !m_at_d) return -1;
+    pnmol_ctx* ctx = f->ctx;
+    QCHECK(ctx, hipSetDevice(ctx->device));
+    const SqConst kc = sq_const(f, dt);
+    hipLaunchKernelGGL(k_sq_mean, dim3((f->d + 255) / 256), dim3(256), 0, ctx->stream, f->mp, f->mean, f->d, kc);
+    std::vector<double> mv(f->D);
+    QCHECK(ctx, hipMemcpyAsync(mv.data(), f->mp, sizeof(double) * f->D, hipMemcpyDeviceToHost, ctx->stream));
+    QCHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int j = 0; j < f->d; ++j) m_at_d[j] = kc.p[0] * mv[(size_t)j * f->n];   // E0 P mp, white.py:192
+    return 0;
+}
+
+int pnmol_sqrt_filter_step(pnmol_sqrt_filter* f, double dt, pnmol_step_out* info) {
+    if (!f || !(dt >= 0.0)) return -1;
+    pnmol_ctx* ctx = f->ctx;
+    QCHECK(ctx, hipSetDevice(ctx->device));
+    if (int rc = sq_step(f, dt, f->norms)) return rc;
+    double nrm[2];
+    QCHECK(ctx, hipMemcpyAsync(nrm, f->norms, sizeof(nrm), hipMemcpyDeviceToHost, ctx->stream));
+    QCHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (info) sq_fill_out(info, f->t, nrm, f->m);
+    return 0;
+}
+
+int pnmol_sqrt_filter_steps(pnmol_sqrt_filter* f, int k, double dt, double* means_kd, double* stds_kd,
+                            pnmol_step_out* info_k) {
+    if (!f || k <= 0 || !(dt >= 0.0)) return -1;
+    pnmol_ctx* ctx = f->ctx;
+    QCHECK(ctx, hipSetDevice(ctx->device));
+    DevBuf dm, ds, dn;
+    if (dm.alloc((size_t)k * f->d) || ds.alloc((size_t)k * f->d) || dn.alloc((size_t)2 * k)) return -4;
+    hipEvent_t e0, e1;
+    QCHECK(ctx, hipEventCreate(&e0));
+    QCHECK(ctx, hipEventCreate(&e1));
+    QCHECK(ctx, hipEventRecord(e0, ctx->stream));
+    int rc = 0;
+    for (int s = 0; s < k && !rc; ++s) {
+        rc = sq_step(f, dt, dn.p + 2 * s);
+        hipLaunchKernelGGL(k_sq_readout, dim3((f->d + 3) / 4), dim3(256), 0, ctx->stream, dm.p + (size_t)s * f->d,
+                           ds.p + (size_t)s * f->d, f->mean, f->Cl, f->d, f->n, f->D);
+    }
+    hipEventRecord(e1, ctx->stream);
+    hipEventSynchronize(e1);
+    hipEventElapsedTime(&f->last_ms, e0, e1);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (rc) return rc;
+    std::vector<double> nrm((size_t)2 * k);
+    QCHECK(ctx, hipMemcpyAsync(nrm.data(), dn.p, sizeof(double) * nrm.size(), hipMemcpyDeviceToHost, ctx->stream));
+    if (means_kd) QCHECK(ctx, hipMemcpyAsync(means_kd, dm.p, sizeof(double) * (size_t)k * f->d, hipMemcpyDeviceToHost, ctx->stream));
+    if (stds_kd) QCHECK(ctx, hipMemcpyAsync(stds_kd, ds.p, sizeof(double) * (size_t)k * f->d, hipMemcpyDeviceToHost, ctx->stream));
+    QCHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (info_k) {
+        const double t0 = f->t - k * dt;
+        for (int s = 0; s < k; ++s) sq_fill_out(info_k + s, t0 + (s + 1) * dt, nrm.data() + 2 * s, f->m);
+    }
+    return 0;
+}
+
+int pnmol_sqrt_filter_last_steps_ms(pnmol_sqrt_filter* f, float* ms) {
+    if (!f || !ms) return -1;
+    *ms = f->last_ms;
+    return 0;
 }
 
 }  // extern "C"

@@ -83,6 +83,16 @@ SYMBOLS = {
                                                              ctypes.c_int, _c_double_p]),
     "pnmol_sqrt_update": (ctypes.c_int, [_vp, _c_double_p, ctypes.c_int, ctypes.c_int, _c_double_p, _c_double_p,
                                          _c_double_p, _c_double_p, _c_double_p]),
+    "pnmol_sqrt_filter_create": (ctypes.c_int, [_vp, ctypes.POINTER(FilterDesc), ctypes.POINTER(_vp)]),
+    "pnmol_sqrt_filter_destroy": (ctypes.c_int, [_vp]),
+    "pnmol_sqrt_filter_set_state": (ctypes.c_int, [_vp, ctypes.c_double, _c_double_p, _c_double_p]),
+    "pnmol_sqrt_filter_get_state": (ctypes.c_int, [_vp, _c_double_p, _c_double_p, _c_double_p]),
+    "pnmol_sqrt_filter_predict_mean": (ctypes.c_int, [_vp, ctypes.c_double, _c_double_p]),
+    "pnmol_sqrt_filter_set_operator": (ctypes.c_int, [_vp, _c_double_p, _c_double_p]),
+    "pnmol_sqrt_filter_step": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.POINTER(StepOut)]),
+    "pnmol_sqrt_filter_steps": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, _c_double_p, _c_double_p,
+                                               ctypes.POINTER(StepOut)]),
+    "pnmol_sqrt_filter_last_steps_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "pnmol_sqrt_update_no_meascov": (ctypes.c_int, [_vp, _c_double_p, ctypes.c_int, ctypes.c_int, _c_double_p,
                                                     _c_double_p, _c_double_p, _c_double_p]),
 }
@@ -356,3 +366,73 @@ class State:
         out = np.empty((D, D))
         self.ctx.check(self.lib.pnmol_state_get_cov(self.handle, _dp(out)), "pnmol_state_get_cov")
         return out
+
+
+class SqrtFilter:
+    """`pnmol_sqrt_filter`: the white-noise EK1 step in square-root (QR) form, one device-resident state."""
+
+    def __init__(self, ctx, *, L, B, E_sqrtm, R_sqrtm, Gamma, num_derivatives):
+        self.ctx = ctx
+        d = L.shape[0]
+        nB = 0 if B is None else B.shape[0]
+        self._keep = [_f64(L, (d, d)), _f64(B if nB else np.zeros((0, d))), _f64(E_sqrtm, (d, d)),
+                      _f64(R_sqrtm if nB else np.zeros((0, 0))), _f64(Gamma, (d, d))]
+        desc = FilterDesc(d=d, num_derivatives=int(num_derivatives), nB=nB, L=_dp(self._keep[0]),
+                          B=_dp(self._keep[1]) if nB else None, E_sqrtm=_dp(self._keep[2]),
+                          R_sqrtm=_dp(self._keep[3]) if nB else None, Gamma=_dp(self._keep[4]), d_state=0)
+        h = _vp()
+        ctx.check(ctx.lib.pnmol_sqrt_filter_create(ctx.handle, ctypes.byref(desc), ctypes.byref(h)),
+                  "pnmol_sqrt_filter_create")
+        self.handle, self.d, self.n, self.m = h, d, int(num_derivatives) + 1, d + nB
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.ctx.lib.pnmol_sqrt_filter_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def set_state(self, t, mean, cov_sqrtm):
+        D = self.n * self.d
+        mean, C = _f64(mean, (self.n, self.d)), _f64(cov_sqrtm, (D, D))
+        self.ctx.check(self.ctx.lib.pnmol_sqrt_filter_set_state(self.handle, float(t), _dp(mean), _dp(C)),
+                       "pnmol_sqrt_filter_set_state")
+
+    def get_state(self, *, factor=True):
+        D = self.n * self.d
+        t, mean = ctypes.c_double(0), np.empty((self.n, self.d))
+        C = np.empty((D, D)) if factor else None
+        self.ctx.check(self.ctx.lib.pnmol_sqrt_filter_get_state(self.handle, ctypes.byref(t), _dp(mean),
+                                                                 _dp(C) if factor else None), "pnmol_sqrt_filter_get_state")
+        return t.value, mean, C
+
+    def predict_mean(self, dt):
+        out = np.empty(self.d)
+        self.ctx.check(self.ctx.lib.pnmol_sqrt_filter_predict_mean(self.handle, float(dt), _dp(out)),
+                       "pnmol_sqrt_filter_predict_mean")
+        return out
+
+    def set_operator(self, M, shift=None):
+        M = _f64(M, (self.d, self.d))
+        sh = None if shift is None else _f64(shift, (self.d,))
+        self.ctx.check(self.ctx.lib.pnmol_sqrt_filter_set_operator(self.handle, _dp(M), None if sh is None else _dp(sh)),
+                       "pnmol_sqrt_filter_set_operator")
+
+    def step(self, dt):
+        info = StepOut()
+        self.ctx.check(self.ctx.lib.pnmol_sqrt_filter_step(self.handle, float(dt), ctypes.byref(info)),
+                       "pnmol_sqrt_filter_step")
+        return info
+
+    def steps(self, k, dt):
+        means, stds = np.empty((k, self.d)), np.empty((k, self.d))
+        infos = (StepOut * k)()
+        self.ctx.check(self.ctx.lib.pnmol_sqrt_filter_steps(self.handle, int(k), float(dt), _dp(means), _dp(stds), infos),
+                       "pnmol_sqrt_filter_steps")
+        return means, stds, list(infos)
+
+    def last_steps_ms(self):
+        ms = ctypes.c_float(0)
+        self.ctx.lib.pnmol_sqrt_filter_last_steps_ms(self.handle, ctypes.byref(ms))
+        return ms.value

@@ -1,0 +1,113 @@
+"""The white-noise EK1 solvers with the step in square-root (QR) form on the GPU.
+
+`pnmol.white.*` advance the covariance (the fast path).  The classes here advance the reference's own state
+`MultivariateNormal(mean, cov_sqrtm)` by the reference's own sequence -- `propagate_cholesky_factor(A @ Cl, Ql)`, then
+`update_sqrt(H, Clp, E)` (white.py:96-146, base/sqrt.py) -- with both QRs on the device (include/pnmol_sqrt.h).  Use them
+when the factor itself is wanted or the covariance form's resolution is not enough; a step costs about 40x the
+covariance form's flops.  `estimate_error` is not evaluated: constant step rule only.  No CPU fallback.
+"""
+
+import numpy as np
+
+from pnmol import _hip, pdefilter, white
+from pnmol.base import rv
+from pnmol.odetools import step as _step
+
+
+class _SqrtFormMixin:
+    _sqrt_filter = None
+    _sqrt_last = None      # the state object whose factor is resident in the device filter
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if not isinstance(self.steprule, _step.Constant):
+            raise TypeError("the square-root form evaluates no error estimate: use the Constant step rule")
+
+    def initialize(self, pde):
+        """The reference's own initialisation (white.py:12-80), its two `update_sqrt` calls on the device: prior
+        kron(Gamma, c I), conditioned on y0 (nugget 1e-10), then on the PDE/BC residual at t0."""
+        from pnmol.base import sqrt as dsqrt
+
+        self.iwp, self.E0, self.E1, gamma = self.initialize_iwp(pde)
+        self._gram = gamma @ gamma.T
+        self._device_pde = pde
+        ctx = self._context or _hip.Context.default()
+        self._sqrt_filter = _hip.SqrtFilter(ctx, L=pde.L, B=pde.B, E_sqrtm=pde.E_sqrtm, R_sqrtm=pde.R_sqrtm, Gamma=gamma,
+                                            num_derivatives=self.num_derivatives)
+        n, d, nB = self.num_derivatives + 1, pde.L.shape[0], pde.B.shape[0]
+        C0_raw = np.kron(gamma, self.diffuse_prior_scale * np.eye(n))
+        C0_y0, k_y0, _ = dsqrt.update_sqrt(self.E0, C0_raw, 1e-10 * np.eye(d), ctx=ctx)
+        m0_y0 = k_y0 @ pde.y0
+        # evaluate_ode at t0 with p0 = E0, p1 = E1 (white.py:42-48): H = [E1 - M E0; B E0] written by index
+        M, shift = self._linearize(pde, m0_y0[0::n], pde.t0)
+        H = np.zeros((d + nB, n * d))
+        H[:d, 0::n] = -M
+        H[np.arange(d), np.arange(d) * n + 1] += 1.0
+        H[d:, 0::n] = pde.B
+        z = H @ m0_y0 + np.concatenate([shift, np.zeros(nB)])
+        E = np.zeros((d + nB, d + nB))
+        E[:d, :d], E[d:, d:] = pde.E_sqrtm, pde.R_sqrtm
+        C0, k, _ = dsqrt.update_sqrt(H, C0_y0, E + 1e-10 * np.eye(d + nB), ctx=ctx)
+        m0 = m0_y0 - k @ z
+        state = pdefilter.PDEFilterState(t=pde.t0, y=rv.MultivariateNormal(m0.reshape((n, d), order="F"), C0),
+                                         error_estimate=None, reference_state=None, diffusion_squared_local=[])
+        self._sqrt_last = None
+        return state
+
+    def _load(self, state, pde):
+        if self._sqrt_filter is None or self._device_pde is not pde:
+            raise RuntimeError("call initialize(pde) before attempt_step (the device model is bound there)")
+        if self._sqrt_last is not state:       # rejected / foreign state: upload it
+            self._sqrt_filter.set_state(state.t, np.asarray(state.y.mean), np.asarray(state.y.cov_sqrtm))
+
+    def attempt_step(self, state, dt, pde):
+        flt = self._sqrt_filter
+        self._load(state, pde)
+        if self.semilinear:
+            m_at = flt.predict_mean(dt)
+            flt.set_operator(*self._linearize(pde, m_at, state.t + dt))
+        info = flt.step(dt)
+        self.last_step_info = info
+        _, mean, C = flt.get_state()
+        new = pdefilter.PDEFilterState(t=state.t + dt, y=rv.MultivariateNormal(mean, C), error_estimate=None,
+                                       reference_state=np.abs(mean[0]), diffusion_squared_local=info.diffusion_squared_local)
+        self._sqrt_last = new
+        return new, dict(num_f_evaluations=1, num_df_evaluations=1)
+
+    def solve_marginals(self, pde, *, num_steps=None):
+        """As `pnmol.white.LinearWhiteNoiseEK1.solve_marginals`, the loop kept on the device in square-root form."""
+        if self.semilinear:
+            raise TypeError("solve_marginals keeps the loop on the device and needs a linear PDE; use solve()")
+        state = self.initialize(pde)
+        self._load(state, pde)
+        flt, dt0 = self._sqrt_filter, self.steprule.first_dt(pde)
+        ts, dts, t, dt = [pde.t0], [], pde.t0, dt0
+        while t < pde.tmax and (num_steps is None or len(dts) < num_steps):
+            dts.append(dt)
+            t = t + dt
+            ts.append(t)
+            dt = min(dt0, pde.tmax - t)
+        C0 = np.asarray(state.y.cov_sqrtm)
+        means, stds, sig = [state.y.mean[0]], [np.sqrt(np.einsum("ij,ij->i", C0, C0)[:: self.num_derivatives + 1])], []
+        i = 0
+        while i < len(dts):
+            j = i
+            while j < len(dts) and dts[j] == dts[i]:
+                j += 1
+            mk, sk, infos = flt.steps(j - i, dts[i])
+            means.extend(mk), stds.extend(sk)
+            sig.extend(o.diffusion_squared_local for o in infos)
+            i = j
+        _, mean, C = flt.get_state()
+        final = pdefilter.PDEFilterState(t=ts[-1], y=rv.MultivariateNormal(mean, C), error_estimate=None,
+                                         reference_state=np.abs(mean[0]), diffusion_squared_local=sig[-1] if sig else [])
+        self._sqrt_last = final
+        return np.array(ts), np.array(means), np.array(stds), np.array(sig), final
+
+
+class LinearWhiteNoiseEK1(_SqrtFormMixin, white.LinearWhiteNoiseEK1):
+    """`pnmol.white.LinearWhiteNoiseEK1` (white.py:169-186), square-root form."""
+
+
+class SemiLinearWhiteNoiseEK1(_SqrtFormMixin, white.SemiLinearWhiteNoiseEK1):
+    """`pnmol.white.SemiLinearWhiteNoiseEK1` (white.py:189-208), square-root form."""

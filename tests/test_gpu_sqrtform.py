@@ -1,0 +1,94 @@
+"""The filter step in square-root (QR) form on the GPU (`pnmol.sqrtform`, include/pnmol_sqrt.h) against the oracle's
+restatement of the reference algorithm as written (white.py:96-146 with base/sqrt.py): same state (mean, cov_sqrtm),
+same sequence of two QRs, so the FACTOR itself is compared (up to the column signs LAPACK leaves arbitrary)."""
+
+import numpy as np
+import pytest
+
+import pnmol
+import pnmol_oracle as o
+from helpers import assert_mean_std_parity, make_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def _canon(C):
+    return C * np.where(np.diag(C) < 0, -1.0, 1.0)[None, :]
+
+
+def _sqrt_solver(nu, dt, semilinear=False, kernel=None):
+    cls = pnmol.sqrtform.SemiLinearWhiteNoiseEK1 if semilinear else pnmol.sqrtform.LinearWhiteNoiseEK1
+    return cls(num_derivatives=nu, steprule=pnmol.odetools.step.Constant(dt),
+               spatial_kernel=kernel or pnmol.kernels.Matern52() + pnmol.kernels.WhiteNoise())
+
+
+@pytest.mark.parametrize("N,nu,bcond", [(32, 2, "dirichlet"), (32, 1, "neumann"), (50, 3, "neumann"), (128, 2, "dirichlet")])
+def test_single_step_from_the_oracles_state(N, nu, bcond):
+    """One attempt_step from the oracle's own initial state: mean, factor, sigma^2."""
+    dt = 2.0 ** -7
+    pde, _, opde, osolver = make_pair(N, nu, dt, 4, bcond=bcond)
+    solver = _sqrt_solver(nu, dt)
+    solver.initialize(pde)
+    ostate = osolver.initialize(opde)
+    state = pnmol.pdefilter.PDEFilterState(t=ostate.t, y=pnmol.base.rv.MultivariateNormal(ostate.y.mean, ostate.y.cov_sqrtm),
+                                           error_estimate=None, reference_state=None, diffusion_squared_local=[])
+    for _ in range(3):
+        new, _ = solver.attempt_step(state, dt, pde)
+        onew, _ = osolver.attempt_step(ostate, dt, opde)
+        np.testing.assert_allclose(new.y.mean, onew.y.mean, rtol=1e-7, atol=1e-9 * np.abs(onew.y.mean).max())
+        C, oC = new.y.cov_sqrtm, _canon(onew.y.cov_sqrtm)
+        assert np.all(np.triu(C, 1) == 0) and np.all(np.diag(C) >= 0)
+        cov, ocov = C @ C.T, oC @ oC.T
+        sd = np.sqrt(np.diag(ocov))
+        sd = np.maximum(sd, 1e-8 * sd.max())      # exactly-zero variances (Dirichlet nodes) are 1e-21-level noise in both
+        assert np.max(np.abs(cov - ocov) / np.outer(sd, sd)) < 1e-6
+        # the factor itself, where it is determined: a noise-free Dirichlet node comes first in the state order with a
+        # pivot of 1e-21, and every later column of ANY triangular factor then carries cov[:, 0] / 1e-21 = rounding
+        # noise of O(1e-4): only C C^T is defined there (checked above); with Neumann conditions the factor is unique
+        if bcond == "neumann":
+            np.testing.assert_allclose(C, oC, rtol=1e-5, atol=1e-8 * np.abs(oC).max())
+        np.testing.assert_allclose(new.diffusion_squared_local, onew.diffusion_squared_local, rtol=1e-6)
+        state, ostate = new, onew
+
+
+@pytest.mark.parametrize("bcond", ["dirichlet", "neumann"])
+def test_solve_matches_oracle(bcond):
+    N, nu, dt, K = 40, 2, 2.0 ** -6, 10
+    pde, _, opde, osolver = make_pair(N, nu, dt, K, bcond=bcond)
+    solver = _sqrt_solver(nu, dt)
+    sol, osol = solver.solve(pde), osolver.solve(opde)
+    om, os_ = o.read_mean_and_std(osol, osolver.E0)
+    assert_mean_std_parity(sol.mean[:, 0], sol.marginal_std[:, 0], om, os_)
+    np.testing.assert_allclose(sol.diffusion_squared_calibrated, osol.diffusion_squared_calibrated, rtol=1e-5)
+    assert sol.cov_sqrtm.shape == osol.cov_sqrtm.shape
+    # square-root form resolves the small standard deviations the covariance form floors at 1e-5 max(std)
+    big = os_[1:] > 1e-9 * os_.max()
+    np.testing.assert_allclose(sol.marginal_std[1:, 0][big], os_[1:][big], rtol=1e-6)
+
+
+def test_device_loop_matches_stepwise_solve_and_covariance_form():
+    N, nu, dt, K = 64, 2, 2.0 ** -7, 8
+    pde, cov_solver, _, _ = make_pair(N, nu, dt, K)
+    solver = _sqrt_solver(nu, dt)
+    t, means, stds, sig, final = solver.solve_marginals(pde)
+    sol = _sqrt_solver(nu, dt).solve(pde)
+    np.testing.assert_allclose(means, sol.mean[:, 0], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(stds[1:], sol.marginal_std[1:, 0], rtol=1e-8, atol=1e-14)
+    np.testing.assert_allclose(np.mean(sig), sol.diffusion_squared_calibrated, rtol=1e-9)
+    tc, mc, sc, sigc, _ = cov_solver.solve_marginals(pde)
+    assert np.array_equal(t, tc)
+    assert_mean_std_parity(mc, sc, means, stds)
+    np.testing.assert_allclose(sigc, sig, rtol=1e-5)
+
+
+def test_semilinear_spruce_budworm():
+    dt, K = 2.0 ** -4, 6
+    pde = pnmol.pde.examples.spruce_budworm_1d_discretized(dx=0.1, tmax=K * dt)
+    opde = o.spruce_budworm_1d_discretized(dx=0.1, tmax=K * dt)
+    k, ok = pnmol.kernels.SquareExponential() + pnmol.kernels.WhiteNoise(), o.SquareExponential() + o.WhiteNoise()
+    sol = _sqrt_solver(2, dt, semilinear=True, kernel=k).solve(pde)
+    osolver = o.WhiteNoiseEK1(num_derivatives=2, steprule=o.Constant(dt), spatial_kernel=ok, semilinear=True,
+                              canonical_factor_signs=True)
+    osol = osolver.solve(opde)
+    om, os_ = o.read_mean_and_std(osol, osolver.E0)
+    assert_mean_std_parity(sol.mean[:, 0], sol.marginal_std[:, 0], om, os_)
