@@ -101,19 +101,32 @@ __global__ __launch_bounds__(FT) void k_qr_factor(double* __restrict__ W, long l
         part += __shfl_xor(part, 32);  // the wave's two row groups
         if (lane < 32) L.red[w * QB + k] = part;
         __syncthreads();
-        double sk = 0.0, sJ = 0.0;
+        double rk[FAN], rJ[FAN];
 #pragma unroll
         for (int ww = 0; ww < FAN; ++ww) {
-            sk += L.red[ww * QB + k];
-            sJ += L.red[ww * QB + J];
+            rk[ww] = L.red[ww * QB + k];
+            rJ[ww] = L.red[ww * QB + J];
         }
-        // dlarfg: H = I - tau v v^T, v = [1; x / (alpha - beta)], beta = -sign(alpha) |(alpha, x)|
+        static_assert(FAN == 8, "pairwise sums below are written for 8 partials");
+        const double sk = ((rk[0] + rk[1]) + (rk[2] + rk[3])) + ((rk[4] + rk[5]) + (rk[6] + rk[7]));
+        const double sJ = ((rJ[0] + rJ[1]) + (rJ[2] + rJ[3])) + ((rJ[4] + rJ[5]) + (rJ[6] + rJ[7]));
+        // dlarfg: H = I - tau v v^T, v = [1; x / (alpha - beta)], beta = -sign(alpha) |(alpha, x)|; with
+        // nrm = |(alpha, x)|: tau = (beta - alpha) / beta = 1 + |alpha| / nrm, 1 / (alpha - beta) = sign(alpha) / (|alpha| + nrm)
+        // -- one rsqrt and one reciprocal on the step's critical path instead of a sqrt and two divisions
         const double alpha = L.rowb[cur][J], aJk = L.rowb[cur][k];
         double beta = alpha, tau = 0.0, scale = 0.0;
         if (sJ != 0.0) {
-            beta = -copysign(sqrt(alpha * alpha + sJ), alpha);
-            tau = (beta - alpha) / beta;
-            scale = 1.0 / (alpha - beta);
+            const double n2 = alpha * alpha + sJ, aa = fabs(alpha);
+            double rn = __builtin_amdgcn_rsq(n2);
+            rn = rn * (1.5 - 0.5 * n2 * rn * rn);          // two Newton steps: full double precision
+            rn = rn * (1.5 - 0.5 * n2 * rn * rn);
+            const double nrm = n2 * rn, den = aa + nrm;
+            double rd = __builtin_amdgcn_rcp(den);
+            rd = rd * (2.0 - den * rd);
+            rd = rd * (2.0 - den * rd);
+            beta = -copysign(nrm, alpha);
+            tau = 1.0 + aa * rn;
+            scale = copysign(rd, alpha);
         }
         const double f = tau * (aJk + sk * scale);  // tau v^T A[:, k]
         if (g == 0) {
