@@ -54,20 +54,30 @@ struct FactorLds {
     double rowb[2][QB];     // row J
 };
 
-// Member q of chunk c at tree level s of panel p.
-__device__ __forceinline__ int member_rb(int p, int s, int c, int q) { return p + s * (FAN * c + q); }
+// The row blocks a panel's reflectors act on ("members"), in tree order: `ntop` consecutive blocks from the panel's own
+// diagonal block p, then blocks bot0, bot0+1, ... up to `cnt` members in all.  Dense matrix: ntop = cnt = nrb - p.  Two
+// stacked triangular blocks (the predict QR): {p, p+1} and the first p+1 blocks of the lower one.
+struct MemberMap {
+    int ntop, bot0, cnt;
+};
+// Member q of chunk c at tree level s of panel p (-1: none).
+__device__ __forceinline__ int member_rb(const MemberMap& mm, int p, int s, int c, int q) {
+    const int idx = s * (FAN * c + q);
+    if (idx >= mm.cnt) return -1;
+    return idx < mm.ntop ? p + idx : mm.bot0 + (idx - mm.ntop);
+}
 
 // Householder QR of one chunk's panel (CR x 32, in LDS).  Column step J, with the inner products of column J against all
 // columns k >= J taken in one pass (s_k = sum_{i>J} A[i][J] A[i][k]; k = J gives the dlarfg sigma), so a step costs two
 // block barriers.  Nothing is updated in place that another thread still reads in the same phase: row J of R goes to
 // L.R, the reflector stays unscaled in A's column J (scale[J] applied at the end).
-__global__ __launch_bounds__(FT) void k_qr_factor(double* __restrict__ W, long ld, int nrb, int p, int s,
+__global__ __launch_bounds__(FT) void k_qr_factor(double* __restrict__ W, long ld, MemberMap mm, int p, int s,
                                                   double* __restrict__ Vws, double* __restrict__ Tws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char qr_lds_raw[];
     FactorLds& L = *reinterpret_cast<FactorLds*>(qr_lds_raw);
     const int c = blockIdx.x, t = threadIdx.x, k = t & 31, g = t >> 5, w = t >> 6, lane = t & 63;
     int nm = 0;
-    for (int q = 0; q < FAN; ++q) nm += member_rb(p, s, c, q) < nrb;
+    for (int q = 0; q < FAN; ++q) nm += member_rb(mm, p, s, c, q) >= 0;
     if (nm == 0 || (nm == 1 && s > 1)) return;  // a lone survivor is already triangular (k_qr_apply skips it too)
     const int rows = nm * QB;
 
@@ -78,7 +88,7 @@ __global__ __launch_bounds__(FT) void k_qr_factor(double* __restrict__ W, long l
     for (int r = 0; r < RPT; ++r) {
         const int i = g + NG * r;
         const int q = i >> 5;
-        a[r] = (q < nm) ? W[((long)member_rb(p, s, c, q) * QB + (i & 31)) * ld + (long)p * QB + k] : 0.0;
+        a[r] = (q < nm) ? W[((long)member_rb(mm, p, s, c, q) * QB + (i & 31)) * ld + (long)p * QB + k] : 0.0;
     }
     if (k == 0) {
 #pragma unroll
@@ -197,7 +207,7 @@ __global__ __launch_bounds__(FT) void k_qr_factor(double* __restrict__ W, long l
     }
     if (g < 2) {
         for (int r = g; r < QB; r += 2)
-            W[((long)member_rb(p, s, c, 0) * QB + r) * ld + (long)p * QB + k] = L.R[r * QB + k];
+            W[((long)member_rb(mm, p, s, c, 0) * QB + r) * ld + (long)p * QB + k] = L.R[r * QB + k];
     }
 }
 
@@ -205,7 +215,7 @@ __global__ __launch_bounds__(FT) void k_qr_factor(double* __restrict__ W, long l
 // wave keeps its 256 x 16 slab of C in registers in the MFMA's B-operand layout (lane (fr, fk) holds C[4s + fk][fr]),
 // which is also the accumulator layout of the 16-row tile s / 4 (row fk + 4 (s % 4)): the last product accumulates
 // straight into the slab.
-__global__ __launch_bounds__(256) void k_qr_apply(double* __restrict__ W, long ld, int nrb, int p, int s,
+__global__ __launch_bounds__(256) void k_qr_apply(double* __restrict__ W, long ld, MemberMap mm, int p, int s,
                                                   const double* __restrict__ Vws, const double* __restrict__ Tws,
                                                   int col0, int ncols) {
     extern __shared__ __attribute__((aligned(16))) unsigned char qr_lds_raw[];
@@ -214,7 +224,7 @@ __global__ __launch_bounds__(256) void k_qr_apply(double* __restrict__ W, long l
     double* sWall = sT + QB * VLD;                        // per wave: 32 x 17
     const int c = blockIdx.x, t = threadIdx.x, w = t >> 6, lane = t & 63, fr = lane & 15, fk = lane >> 4;
     int nm = 0;
-    for (int q = 0; q < FAN; ++q) nm += member_rb(p, s, c, q) < nrb;
+    for (int q = 0; q < FAN; ++q) nm += member_rb(mm, p, s, c, q) >= 0;
     if (nm == 0 || (nm == 1 && s > 1)) return;
     const double* Vg = Vws + (long)c * CR * QB;
     const double* Tg = Tws + (long)c * QB * QB;
@@ -228,7 +238,7 @@ __global__ __launch_bounds__(256) void k_qr_apply(double* __restrict__ W, long l
 #pragma unroll
     for (int st = 0; st < CR / 4; ++st) {
         const int i = 4 * st + fk, q = i >> 5;
-        cs[st] = (q < nm) ? W[((long)member_rb(p, s, c, q) * QB + (i & 31)) * ld + col] : 0.0;
+        cs[st] = (q < nm) ? W[((long)member_rb(mm, p, s, c, q) * QB + (i & 31)) * ld + col] : 0.0;
     }
     __syncthreads();
 
@@ -278,7 +288,7 @@ __global__ __launch_bounds__(256) void k_qr_apply(double* __restrict__ W, long l
 #pragma unroll
     for (int st = 0; st < CR / 4; ++st) {
         const int i = 4 * st + fk, q = i >> 5;
-        if (q < nm) W[((long)member_rb(p, s, c, q) * QB + (i & 31)) * ld + col] = cs[st];
+        if (q < nm) W[((long)member_rb(mm, p, s, c, q) * QB + (i & 31)) * ld + col] = cs[st];
     }
 }
 
@@ -432,18 +442,28 @@ int qr_configure(pnmol_ctx* ctx) {
     return 0;
 }
 
-// R factor of the padded work matrix, in place (upper triangle of W's leading ld x ld block).
-int qr_inplace(pnmol_ctx* ctx, const QrPlan& pl) {
+// R factor of the padded work matrix, in place (upper triangle of W's leading ld x ld block).  tri_bot0 > 0: the matrix
+// is two stacked blocks, rows [0, 32 tri_bot0) and from row block tri_bot0 on, the upper one upper triangular up to
+// `bulge` < 32 rows below its diagonal, the lower one upper triangular: panel p then only touches the member list above.
+int qr_inplace(pnmol_ctx* ctx, const QrPlan& pl, int tri_bot0 = 0) {
     for (int p = 0; p < pl.ncb; ++p) {
-        const int a = pl.nrb - p;
+        MemberMap mm;
+        if (tri_bot0 > 0) {
+            mm.ntop = std::min(2, tri_bot0 - p);
+            mm.bot0 = tri_bot0;
+            mm.cnt = mm.ntop + std::min(p + 1, pl.nrb - tri_bot0);
+        } else {
+            mm.ntop = mm.cnt = pl.nrb - p;
+            mm.bot0 = 0;
+        }
         const int ntrail = pl.ld - (p + 1) * QB;
         for (int s = 1;; s *= FAN) {
-            const int nmem = (a + s - 1) / s, nch = (nmem + FAN - 1) / FAN;
-            hipLaunchKernelGGL(k_qr_factor, dim3(nch), dim3(FT), kFactorLds, ctx->stream, pl.W, (long)pl.ld, pl.nrb, p, s,
+            const int nmem = (mm.cnt + s - 1) / s, nch = (nmem + FAN - 1) / FAN;
+            hipLaunchKernelGGL(k_qr_factor, dim3(nch), dim3(FT), kFactorLds, ctx->stream, pl.W, (long)pl.ld, mm, p, s,
                                pl.Vws, pl.Tws);
             if (ntrail > 0)
                 hipLaunchKernelGGL(k_qr_apply, dim3(nch, (ntrail + 63) / 64), dim3(256), kApplyLds, ctx->stream, pl.W,
-                                   (long)pl.ld, pl.nrb, p, s, pl.Vws, pl.Tws, (p + 1) * QB, ntrail);
+                                   (long)pl.ld, mm, p, s, pl.Vws, pl.Tws, (p + 1) * QB, ntrail);
             if (nch == 1) break;
         }
     }
@@ -881,6 +901,7 @@ struct pnmol_sqrt_filter {
            *norms = nullptr;
     double t = 0.0;
     QrPlan q1, q2;
+    bool cl_tri = false;        // the resident factor is lower triangular: the predict QR can use the structured member lists
     std::vector<double> hB;     // boundary rows, kept for set_operator
     float last_ms = -1.f;
 };
@@ -934,9 +955,11 @@ int sq_step(pnmol_sqrt_filter* f, double dt, double* norms_out) {
     hipLaunchKernelGGL(k_sq_rows, dim3((D + 255) / 256, d), dim3(256), 0, st, f->T1, f->Cl, d, D, kc);
     QCHECK(ctx, hipMemsetAsync(q1.W, 0, sizeof(double) * (size_t)q1.Mp * q1.ld, st));
     hipLaunchKernelGGL(k_copy_t, tiles(D, D), dim3(256), 0, st, q1.W, (long)q1.ld, f->T1, (long)D, D, D);
-    QCHECK(ctx, hipMemcpy2DAsync(q1.W + (long)D * q1.ld, sizeof(double) * q1.ld, f->QlT, sizeof(double) * D,
+    const int Dtop = (D + QB - 1) / QB * QB;   // the lower block starts on a row-block boundary
+    QCHECK(ctx, hipMemcpy2DAsync(q1.W + (long)Dtop * q1.ld, sizeof(double) * q1.ld, f->QlT, sizeof(double) * D,
                                  sizeof(double) * D, D, hipMemcpyDeviceToDevice, st));
-    if (int rc = qr_inplace(ctx, q1)) return rc;
+    // (A Pinv Cl)^T is upper triangular up to the n x n point blocks when Cl is lower triangular, Ql^T exactly
+    if (int rc = qr_inplace(ctx, q1, f->cl_tri ? Dtop / QB : 0)) return rc;
     // update (white.py:104, :120-123): QR of [[R H^T, R], [E^T, 0]]
     QCHECK(ctx, hipMemsetAsync(q2.W, 0, sizeof(double) * (size_t)q2.Mp * q2.ld, st));
     hipLaunchKernelGGL(k_rht, tiles(m, D), dim3(256), 0, st, q2.W, (long)q2.ld, q1.W, (long)q1.ld, f->Hraw, D, m, kc);
@@ -954,6 +977,7 @@ int sq_step(pnmol_sqrt_filter* f, double dt, double* norms_out) {
     hipLaunchKernelGGL(k_sq_state_out, tiles(D, D), dim3(256), 0, st, f->Cl, D, q2.W, (long)q2.ld, m, kc);
     QCHECK(ctx, hipGetLastError());
     f->t += dt;
+    f->cl_tri = true;   // P R3^T
     return 0;
 }
 
@@ -1027,7 +1051,7 @@ int pnmol_sqrt_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmo
             !alloc(&f->QlT, (size_t)D * D) || !alloc(&f->mean, D) || !alloc(&f->Cl, (size_t)D * D) ||
             !alloc(&f->T1, (size_t)D * D) || !alloc(&f->mp, D) || !alloc(&f->z, m) || !alloc(&f->y, m) ||
             !alloc(&f->x, m) || !alloc(&f->norms, 2)) { rc = -4; break; }
-        if ((rc = qr_plan_alloc(ctx, 2 * D, D, &f->q1))) { rc = -4; break; }
+        if ((rc = qr_plan_alloc(ctx, (D + QB - 1) / QB * QB + D, D, &f->q1))) { rc = -4; break; }
         if ((rc = qr_plan_alloc(ctx, D + m, m + D, &f->q2))) { rc = -4; break; }
         // Ql^T = (Gamma (x) Lq)^T (base/iwp.py:32-53), E^T = blockdiag(E_sqrtm, R_sqrtm)^T (white.py:184)
         std::vector<double> QlT((size_t)D * D, 0.0), EtT((size_t)m * m, 0.0);
@@ -1073,6 +1097,11 @@ int pnmol_sqrt_filter_set_state(pnmol_sqrt_filter* f, double t, const double* me
     QCHECK(ctx, hipMemcpyAsync(f->Cl, cov_sqrtm_DD, sizeof(double) * (size_t)f->D * f->D, hipMemcpyHostToDevice, ctx->stream));
     QCHECK(ctx, hipStreamSynchronize(ctx->stream));
     f->t = t;
+    bool tri = true;
+    for (int i = 0; i < f->D && tri; ++i)
+        for (int j = i + 1; j < f->D; ++j)
+            if (cov_sqrtm_DD[(size_t)i * f->D + j] != 0.0) { tri = false; break; }
+    f->cl_tri = tri;
     return 0;
 }
 

@@ -92,3 +92,21 @@ def test_semilinear_spruce_budworm():
     osol = osolver.solve(opde)
     om, os_ = o.read_mean_and_std(osol, osolver.E0)
     assert_mean_std_parity(sol.mean[:, 0], sol.marginal_std[:, 0], om, os_)
+
+
+def test_structured_and_dense_predict_agree():
+    """A non-triangular factor of the same covariance takes the dense member lists in the predict QR, a triangular one the
+    structured lists: same step result."""
+    N, nu, dt = 45, 2, 2.0 ** -7
+    pde, _, _, _ = make_pair(N, nu, dt, 2, bcond="neumann")
+    solver = _sqrt_solver(nu, dt)
+    s0 = solver.initialize(pde)
+    C = np.asarray(s0.y.cov_sqrtm)
+    assert np.all(np.triu(C, 1) == 0)
+    a, _ = solver.attempt_step(s0, dt, pde)
+    rng = np.random.default_rng(0)
+    Q, _ = np.linalg.qr(rng.standard_normal(C.shape))
+    s1 = s0._replace(y=pnmol.base.rv.MultivariateNormal(s0.y.mean, C @ Q))     # same covariance, dense factor
+    b, _ = solver.attempt_step(s1, dt, pde)
+    np.testing.assert_allclose(a.y.mean, b.y.mean, rtol=1e-9, atol=1e-12 * np.abs(a.y.mean).max())
+    np.testing.assert_allclose(a.y.cov_sqrtm, b.y.cov_sqrtm, rtol=1e-6, atol=1e-9 * np.abs(a.y.cov_sqrtm).max())
