@@ -894,7 +894,7 @@ __global__ __launch_bounds__(256) void k_sq_readout(double* __restrict__ means, 
 
 struct pnmol_sqrt_filter {
     pnmol_ctx* ctx = nullptr;
-    int d = 0, n = 0, nu = 0, nB = 0, m = 0, D = 0;
+    int d = 0, ds = 0, n = 0, nu = 0, nB = 0, m = 0, D = 0;   // ds = state components (d, or 2d: latent-force model), D = n ds
     double A1[SQN * SQN] = {0};
     double *Hraw = nullptr, *shift = nullptr, *EtT = nullptr, *QlT = nullptr;
     double *mean = nullptr, *Cl = nullptr, *T1 = nullptr, *mp = nullptr, *z = nullptr, *y = nullptr, *x = nullptr,
@@ -928,15 +928,15 @@ SqConst sq_const(const pnmol_sqrt_filter* f, double dt) {
 
 // Hraw = [E1 - M E0; B E0] (white.py:169-186 with E0 P, E1 P factored into the per-step column scaling) and shift
 int sq_upload_operator(pnmol_sqrt_filter* f, const double* M, const double* shift_d) {
-    const int d = f->d, n = f->n, m = f->m, D = f->D, nB = f->nB;
+    const int d = f->d, ds = f->ds, n = f->n, m = f->m, D = f->D, nB = f->nB;
     std::vector<double> H((size_t)m * D, 0.0), sh(m, 0.0);
-    for (int i = 0; i < d; ++i) {
-        for (int j = 0; j < d; ++j) H[(size_t)i * D + (size_t)j * n] = -M[(size_t)i * d + j];
+    for (int i = 0; i < d; ++i) {   // M is (d, ds): [J_x + L] or, latent-force model, [J_x + L, I] (latent.py:253-257)
+        for (int j = 0; j < ds; ++j) H[(size_t)i * D + (size_t)j * n] = -M[(size_t)i * ds + j];
         H[(size_t)i * D + (size_t)i * n + 1] += 1.0;
         if (shift_d) sh[i] = shift_d[i];
     }
     for (int i = 0; i < nB; ++i)
-        for (int j = 0; j < d; ++j) H[(size_t)(d + i) * D + (size_t)j * n] = f->hB[(size_t)i * d + j];
+        for (int j = 0; j < ds; ++j) H[(size_t)(d + i) * D + (size_t)j * n] = f->hB[(size_t)i * ds + j];
     pnmol_ctx* ctx = f->ctx;
     QCHECK(ctx, hipMemcpyAsync(f->Hraw, H.data(), sizeof(double) * H.size(), hipMemcpyHostToDevice, ctx->stream));
     QCHECK(ctx, hipMemcpyAsync(f->shift, sh.data(), sizeof(double) * m, hipMemcpyHostToDevice, ctx->stream));
@@ -947,7 +947,7 @@ int sq_upload_operator(pnmol_sqrt_filter* f, const double* M, const double* shif
 int sq_step(pnmol_sqrt_filter* f, double dt, double* norms_out) {
     pnmol_ctx* ctx = f->ctx;
     hipStream_t st = ctx->stream;
-    const int d = f->d, n = f->n, m = f->m, D = f->D;
+    const int d = f->ds, n = f->n, m = f->m, D = f->D;   // d: state components here
     const SqConst kc = sq_const(f, dt);
     const QrPlan &q1 = f->q1, &q2 = f->q2;
     // predict (white.py:101-103, :114): mp = A Pinv m, Cl- = R^T of [(A Pinv Cl)^T; Ql^T]
@@ -1012,20 +1012,21 @@ int pnmol_sqrt_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmo
         ctx->err = "pnmol_sqrt_filter_create: bad descriptor";
         return -1;
     }
-    if (desc->d_state != 0 && desc->d_state != d) {
-        ctx->err = "pnmol_sqrt_filter_create: the square-root form is built for the white-noise model (d_state = d)";
+    const int ds = desc->d_state ? desc->d_state : d;
+    if (ds != d && ds != 2 * d) {
+        ctx->err = "pnmol_sqrt_filter_create: d_state must be 0, d (white-noise model) or 2d (latent-force model)";
         return -1;
     }
     QCHECK(ctx, hipSetDevice(ctx->device));
     if (int rc = qr_configure(ctx)) return rc;
-    const int m = d + nB, D = n * d;
+    const int m = d + nB, D = n * ds;
     if (sizeof(double) * (2 * (size_t)((m + 31) / 32 * 32) + 32 * 33 + 160) > 160 * 1024) {
         ctx->err = "pnmol_sqrt_filter_create: m too large for the single-block triangular solve";
         return -1;
     }
     pnmol_sqrt_filter* f = new pnmol_sqrt_filter();
-    f->ctx = ctx, f->d = d, f->n = n, f->nu = nu, f->nB = nB, f->m = m, f->D = D;
-    if (nB) f->hB.assign(desc->B, desc->B + (size_t)nB * d);
+    f->ctx = ctx, f->d = d, f->ds = ds, f->n = n, f->nu = nu, f->nB = nB, f->m = m, f->D = D;
+    if (nB) f->hB.assign(desc->B, desc->B + (size_t)nB * ds);
     double Q1[SQN * SQN] = {0}, Lq[SQN * SQN] = {0};
     for (int a = 0; a < n; ++a)
         for (int b = 0; b < n; ++b) {   // base/iwp.py:13-30: flip both axes of pascal (lower) and hilbert
@@ -1055,9 +1056,9 @@ int pnmol_sqrt_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmo
         if ((rc = qr_plan_alloc(ctx, D + m, m + D, &f->q2))) { rc = -4; break; }
         // Ql^T = (Gamma (x) Lq)^T (base/iwp.py:32-53), E^T = blockdiag(E_sqrtm, R_sqrtm)^T (white.py:184)
         std::vector<double> QlT((size_t)D * D, 0.0), EtT((size_t)m * m, 0.0);
-        for (int j = 0; j < d; ++j)
+        for (int j = 0; j < ds; ++j)
             for (int j2 = 0; j2 <= j; ++j2) {
-                const double gjj = desc->Gamma[(size_t)j * d + j2];
+                const double gjj = desc->Gamma[(size_t)j * ds + j2];
                 if (gjj == 0.0) continue;
                 for (int a = 0; a < n; ++a)
                     for (int b = 0; b <= a; ++b)
@@ -1092,7 +1093,7 @@ int pnmol_sqrt_filter_set_state(pnmol_sqrt_filter* f, double t, const double* me
     QCHECK(ctx, hipSetDevice(ctx->device));
     std::vector<double> mv(f->D);
     for (int a = 0; a < f->n; ++a)
-        for (int j = 0; j < f->d; ++j) mv[(size_t)j * f->n + a] = mean_nd[(size_t)a * f->d + j];   // reshape(-1, order="F")
+        for (int j = 0; j < f->ds; ++j) mv[(size_t)j * f->n + a] = mean_nd[(size_t)a * f->ds + j];   // reshape(-1, order="F")
     QCHECK(ctx, hipMemcpyAsync(f->mean, mv.data(), sizeof(double) * f->D, hipMemcpyHostToDevice, ctx->stream));
     QCHECK(ctx, hipMemcpyAsync(f->Cl, cov_sqrtm_DD, sizeof(double) * (size_t)f->D * f->D, hipMemcpyHostToDevice, ctx->stream));
     QCHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1115,7 +1116,7 @@ int pnmol_sqrt_filter_get_state(pnmol_sqrt_filter* f, double* t, double* mean_nd
         QCHECK(ctx, hipMemcpyAsync(mv.data(), f->mean, sizeof(double) * f->D, hipMemcpyDeviceToHost, ctx->stream));
         QCHECK(ctx, hipStreamSynchronize(ctx->stream));
         for (int a = 0; a < f->n; ++a)
-            for (int j = 0; j < f->d; ++j) mean_nd[(size_t)a * f->d + j] = mv[(size_t)j * f->n + a];
+            for (int j = 0; j < f->ds; ++j) mean_nd[(size_t)a * f->ds + j] = mv[(size_t)j * f->n + a];
     }
     if (cov_sqrtm_DD) {
         QCHECK(ctx, hipMemcpyAsync(cov_sqrtm_DD, f->Cl, sizeof(double) * (size_t)f->D * f->D, hipMemcpyDeviceToHost, ctx->stream));
@@ -1129,7 +1130,7 @@ int pnmol_sqrt_filter_predict_mean(pnmol_sqrt_filter* f, double dt, double* m_at
     pnmol_ctx* ctx = f->ctx;
     QCHECK(ctx, hipSetDevice(ctx->device));
     const SqConst kc = sq_const(f, dt);
-    hipLaunchKernelGGL(k_sq_mean, dim3((f->d + 255) / 256), dim3(256), 0, ctx->stream, f->mp, f->mean, f->d, kc);
+    hipLaunchKernelGGL(k_sq_mean, dim3((f->ds + 255) / 256), dim3(256), 0, ctx->stream, f->mp, f->mean, f->ds, kc);
     std::vector<double> mv(f->D);
     QCHECK(ctx, hipMemcpyAsync(mv.data(), f->mp, sizeof(double) * f->D, hipMemcpyDeviceToHost, ctx->stream));
     QCHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1154,8 +1155,9 @@ int pnmol_sqrt_filter_steps(pnmol_sqrt_filter* f, int k, double dt, double* mean
     if (!f || k <= 0 || !(dt >= 0.0)) return -1;
     pnmol_ctx* ctx = f->ctx;
     QCHECK(ctx, hipSetDevice(ctx->device));
-    DevBuf dm, ds, dn;
-    if (dm.alloc((size_t)k * f->d) || ds.alloc((size_t)k * f->d) || dn.alloc((size_t)2 * k)) return -4;
+    const int w = f->ds;   // read-out width: every state component (u, and eps behind it in the latent-force model)
+    DevBuf dm, dsd, dn;
+    if (dm.alloc((size_t)k * w) || dsd.alloc((size_t)k * w) || dn.alloc((size_t)2 * k)) return -4;
     hipEvent_t e0, e1;
     QCHECK(ctx, hipEventCreate(&e0));
     QCHECK(ctx, hipEventCreate(&e1));
@@ -1163,8 +1165,8 @@ int pnmol_sqrt_filter_steps(pnmol_sqrt_filter* f, int k, double dt, double* mean
     int rc = 0;
     for (int s = 0; s < k && !rc; ++s) {
         rc = sq_step(f, dt, dn.p + 2 * s);
-        hipLaunchKernelGGL(k_sq_readout, dim3((f->d + 3) / 4), dim3(256), 0, ctx->stream, dm.p + (size_t)s * f->d,
-                           ds.p + (size_t)s * f->d, f->mean, f->Cl, f->d, f->n, f->D);
+        hipLaunchKernelGGL(k_sq_readout, dim3((w + 3) / 4), dim3(256), 0, ctx->stream, dm.p + (size_t)s * w,
+                           dsd.p + (size_t)s * w, f->mean, f->Cl, w, f->n, f->D);
     }
     hipEventRecord(e1, ctx->stream);
     hipEventSynchronize(e1);
@@ -1174,8 +1176,8 @@ int pnmol_sqrt_filter_steps(pnmol_sqrt_filter* f, int k, double dt, double* mean
     if (rc) return rc;
     std::vector<double> nrm((size_t)2 * k);
     QCHECK(ctx, hipMemcpyAsync(nrm.data(), dn.p, sizeof(double) * nrm.size(), hipMemcpyDeviceToHost, ctx->stream));
-    if (means_kd) QCHECK(ctx, hipMemcpyAsync(means_kd, dm.p, sizeof(double) * (size_t)k * f->d, hipMemcpyDeviceToHost, ctx->stream));
-    if (stds_kd) QCHECK(ctx, hipMemcpyAsync(stds_kd, ds.p, sizeof(double) * (size_t)k * f->d, hipMemcpyDeviceToHost, ctx->stream));
+    if (means_kd) QCHECK(ctx, hipMemcpyAsync(means_kd, dm.p, sizeof(double) * (size_t)k * w, hipMemcpyDeviceToHost, ctx->stream));
+    if (stds_kd) QCHECK(ctx, hipMemcpyAsync(stds_kd, dsd.p, sizeof(double) * (size_t)k * w, hipMemcpyDeviceToHost, ctx->stream));
     QCHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (info_k) {
         const double t0 = f->t - k * dt;

@@ -372,18 +372,20 @@ class SqrtFilter:
     """`pnmol_sqrt_filter`: the white-noise EK1 step in square-root (QR) form, one device-resident state."""
 
     def __init__(self, ctx, *, L, B, E_sqrtm, R_sqrtm, Gamma, num_derivatives):
+        """L (d, ds), B (nB, ds), Gamma (ds, ds) with ds = d (white-noise) or 2d (latent-force: [L, I], [B, 0],
+        blockdiag(chol K, E_sqrtm), zero noise factors) -- the conventions of `Filter`."""
         self.ctx = ctx
-        d = L.shape[0]
+        d, ds = L.shape
         nB = 0 if B is None else B.shape[0]
-        self._keep = [_f64(L, (d, d)), _f64(B if nB else np.zeros((0, d))), _f64(E_sqrtm, (d, d)),
-                      _f64(R_sqrtm if nB else np.zeros((0, 0))), _f64(Gamma, (d, d))]
+        self._keep = [_f64(L, (d, ds)), _f64(B if nB else np.zeros((0, ds))), _f64(E_sqrtm, (d, d)),
+                      _f64(R_sqrtm if nB else np.zeros((0, 0))), _f64(Gamma, (ds, ds))]
         desc = FilterDesc(d=d, num_derivatives=int(num_derivatives), nB=nB, L=_dp(self._keep[0]),
                           B=_dp(self._keep[1]) if nB else None, E_sqrtm=_dp(self._keep[2]),
-                          R_sqrtm=_dp(self._keep[3]) if nB else None, Gamma=_dp(self._keep[4]), d_state=0)
+                          R_sqrtm=_dp(self._keep[3]) if nB else None, Gamma=_dp(self._keep[4]), d_state=ds)
         h = _vp()
         ctx.check(ctx.lib.pnmol_sqrt_filter_create(ctx.handle, ctypes.byref(desc), ctypes.byref(h)),
                   "pnmol_sqrt_filter_create")
-        self.handle, self.d, self.n, self.m = h, d, int(num_derivatives) + 1, d + nB
+        self.handle, self.d, self.ds, self.n, self.m = h, d, ds, int(num_derivatives) + 1, d + nB
 
     def __del__(self):
         try:
@@ -394,14 +396,14 @@ class SqrtFilter:
             pass
 
     def set_state(self, t, mean, cov_sqrtm):
-        D = self.n * self.d
-        mean, C = _f64(mean, (self.n, self.d)), _f64(cov_sqrtm, (D, D))
+        D = self.n * self.ds
+        mean, C = _f64(mean, (self.n, self.ds)), _f64(cov_sqrtm, (D, D))
         self.ctx.check(self.ctx.lib.pnmol_sqrt_filter_set_state(self.handle, float(t), _dp(mean), _dp(C)),
                        "pnmol_sqrt_filter_set_state")
 
     def get_state(self, *, factor=True):
-        D = self.n * self.d
-        t, mean = ctypes.c_double(0), np.empty((self.n, self.d))
+        D = self.n * self.ds
+        t, mean = ctypes.c_double(0), np.empty((self.n, self.ds))
         C = np.empty((D, D)) if factor else None
         self.ctx.check(self.ctx.lib.pnmol_sqrt_filter_get_state(self.handle, ctypes.byref(t), _dp(mean),
                                                                  _dp(C) if factor else None), "pnmol_sqrt_filter_get_state")
@@ -414,7 +416,7 @@ class SqrtFilter:
         return out
 
     def set_operator(self, M, shift=None):
-        M = _f64(M, (self.d, self.d))
+        M = _f64(M, (self.d, self.ds))
         sh = None if shift is None else _f64(shift, (self.d,))
         self.ctx.check(self.ctx.lib.pnmol_sqrt_filter_set_operator(self.handle, _dp(M), None if sh is None else _dp(sh)),
                        "pnmol_sqrt_filter_set_operator")
@@ -426,7 +428,7 @@ class SqrtFilter:
         return info
 
     def steps(self, k, dt):
-        means, stds = np.empty((k, self.d)), np.empty((k, self.d))
+        means, stds = np.empty((k, self.ds)), np.empty((k, self.ds))
         infos = (StepOut * k)()
         self.ctx.check(self.ctx.lib.pnmol_sqrt_filter_steps(self.handle, int(k), float(dt), _dp(means), _dp(stds), infos),
                        "pnmol_sqrt_filter_steps")

@@ -9,7 +9,9 @@ covariance form's flops.  `estimate_error` is not evaluated: constant step rule 
 
 import numpy as np
 
-from pnmol import _hip, pdefilter, white
+import scipy.linalg
+
+from pnmol import _hip, latent, pdefilter, white
 from pnmol.base import rv
 from pnmol.odetools import step as _step
 
@@ -54,6 +56,9 @@ class _SqrtFormMixin:
         self._sqrt_last = None
         return state
 
+    def _stack(self, M):
+        return M                                   # white-noise model: rows of -(M E0 u)
+
     def _load(self, state, pde):
         if self._sqrt_filter is None or self._device_pde is not pde:
             raise RuntimeError("call initialize(pde) before attempt_step (the device model is bound there)")
@@ -65,14 +70,19 @@ class _SqrtFormMixin:
         self._load(state, pde)
         if self.semilinear:
             m_at = flt.predict_mean(dt)
-            flt.set_operator(*self._linearize(pde, m_at, state.t + dt))
+            M, shift = self._linearize(pde, m_at, state.t + dt)
+            flt.set_operator(self._stack(M), shift)
         info = flt.step(dt)
         self.last_step_info = info
         _, mean, C = flt.get_state()
         new = pdefilter.PDEFilterState(t=state.t + dt, y=rv.MultivariateNormal(mean, C), error_estimate=None,
-                                       reference_state=np.abs(mean[0]), diffusion_squared_local=info.diffusion_squared_local)
+                                       reference_state=self._reference_state(mean), diffusion_squared_local=info.diffusion_squared_local)
         self._sqrt_last = new
         return new, dict(num_f_evaluations=1, num_df_evaluations=1)
+
+    @staticmethod
+    def _reference_state(mean):
+        return np.abs(mean[0])                     # white.py:141
 
     def solve_marginals(self, pde, *, num_steps=None):
         """As `pnmol.white.LinearWhiteNoiseEK1.solve_marginals`, the loop kept on the device in square-root form."""
@@ -88,19 +98,20 @@ class _SqrtFormMixin:
             ts.append(t)
             dt = min(dt0, pde.tmax - t)
         C0 = np.asarray(state.y.cov_sqrtm)
-        means, stds, sig = [state.y.mean[0]], [np.sqrt(np.einsum("ij,ij->i", C0, C0)[:: self.num_derivatives + 1])], []
+        d = pde.L.shape[0]                         # (the latent-force state carries eps behind u)
+        means, stds, sig = [state.y.mean[0][:d]], [np.sqrt(np.einsum("ij,ij->i", C0, C0)[:: self.num_derivatives + 1][:d])], []
         i = 0
         while i < len(dts):
             j = i
             while j < len(dts) and dts[j] == dts[i]:
                 j += 1
             mk, sk, infos = flt.steps(j - i, dts[i])
-            means.extend(mk), stds.extend(sk)
+            means.extend(mk[:, :d]), stds.extend(sk[:, :d])
             sig.extend(o.diffusion_squared_local for o in infos)
             i = j
         _, mean, C = flt.get_state()
         final = pdefilter.PDEFilterState(t=ts[-1], y=rv.MultivariateNormal(mean, C), error_estimate=None,
-                                         reference_state=np.abs(mean[0]), diffusion_squared_local=sig[-1] if sig else [])
+                                         reference_state=self._reference_state(mean), diffusion_squared_local=sig[-1] if sig else [])
         self._sqrt_last = final
         return np.array(ts), np.array(means), np.array(stds), np.array(sig), final
 
@@ -111,3 +122,57 @@ class LinearWhiteNoiseEK1(_SqrtFormMixin, white.LinearWhiteNoiseEK1):
 
 class SemiLinearWhiteNoiseEK1(_SqrtFormMixin, white.SemiLinearWhiteNoiseEK1):
     """`pnmol.white.SemiLinearWhiteNoiseEK1` (white.py:189-208), square-root form."""
+
+
+class _SqrtFormLatentMixin(_SqrtFormMixin):
+    """Latent-force model (latent.py:11-292) in square-root form: the stack [u; eps] is one state of 2d components."""
+
+    def _stack(self, M):
+        return self._stacked_operator(M)           # rows of -(M E0 u + E0 eps), latent.py:253-257
+
+    @staticmethod
+    def _reference_state(mean):
+        return None                                # latent.py:224
+
+    def initialize(self, pde):
+        """The reference's own initialisation (latent.py:20-134), its two `update_sqrt` calls (nuggets 1e-6) on the device."""
+        from pnmol.base import sqrt as dsqrt
+        from pnmol.base import stacked_ssm
+
+        self.state_iwp, self.lf_iwp, self.E0, self.E1, gamma = self.initialize_iwp_latent(pde)
+        self.iwp = self.state_iwp
+        self.ssm = stacked_ssm.StackedSSM(processes=[self.state_iwp, self.lf_iwp])
+        self._device_pde = pde
+        ctx = self._context or _hip.Context.default()
+        n, d, nB = self.num_derivatives + 1, pde.L.shape[0], pde.B.shape[0]
+        D = n * d
+        E = np.asarray(pde.E_sqrtm, dtype=np.float64)
+        self._sqrt_filter = _hip.SqrtFilter(
+            ctx, L=self._stacked_operator(pde.L), B=np.hstack((pde.B, np.zeros((nB, d)))), E_sqrtm=np.zeros((d, d)),
+            R_sqrtm=np.zeros((nB, nB)), Gamma=scipy.linalg.block_diag(gamma, E), num_derivatives=self.num_derivatives)
+        c0 = self.diffuse_prior_scale * np.eye(n)
+        C_state, k_y0, _ = dsqrt.update_sqrt(self.E0, np.kron(gamma, c0), 1e-6 * np.eye(d), ctx=ctx)
+        m_stack = np.concatenate([k_y0 @ pde.y0, np.zeros(D)])
+        C_block = scipy.linalg.block_diag(C_state, np.kron(E, c0))
+        # evaluate_ode at t0 (latent.py:88-98): H = [[E1 - M E0, -E0], [B E0, 0]] written by index
+        M, shift = self._linearize(pde, m_stack[0:D:n], pde.t0)
+        H = np.zeros((d + nB, 2 * D))
+        H[:d, 0:D:n] = -M
+        H[np.arange(d), np.arange(d) * n + 1] += 1.0
+        H[np.arange(d), D + np.arange(d) * n] = -1.0
+        H[d:, 0:D:n] = pde.B
+        z = H @ m_stack + np.concatenate([shift, np.zeros(nB)])
+        C0, k, _ = dsqrt.update_sqrt(H, C_block, 1e-6 * np.eye(d + nB), ctx=ctx)
+        m0 = m_stack - k @ z
+        mean = np.concatenate([m0[:D].reshape((n, d), order="F"), m0[D:].reshape((n, d), order="F")], axis=1)
+        self._sqrt_last = None
+        return pdefilter.PDEFilterState(t=pde.t0, y=rv.MultivariateNormal(mean, C0), error_estimate=None,
+                                        reference_state=None, diffusion_squared_local=[])
+
+
+class LinearLatentForceEK1(_SqrtFormLatentMixin, latent.LinearLatentForceEK1):
+    """`pnmol.latent.LinearLatentForceEK1` (latent.py:241-263), square-root form."""
+
+
+class SemiLinearLatentForceEK1(_SqrtFormLatentMixin, latent.SemiLinearLatentForceEK1):
+    """`pnmol.latent.SemiLinearLatentForceEK1` (latent.py:266-292), square-root form."""

@@ -110,3 +110,45 @@ def test_structured_and_dense_predict_agree():
     b, _ = solver.attempt_step(s1, dt, pde)
     np.testing.assert_allclose(a.y.mean, b.y.mean, rtol=1e-9, atol=1e-12 * np.abs(a.y.mean).max())
     np.testing.assert_allclose(a.y.cov_sqrtm, b.y.cov_sqrtm, rtol=1e-6, atol=1e-9 * np.abs(a.y.cov_sqrtm).max())
+
+
+# ---- latent-force model in square-root form (latent.py:20-233) -------------------------------------------------------
+@pytest.mark.parametrize("bcond,semilinear", [("neumann", False), ("dirichlet", False), ("neumann", True)])
+def test_latent_solve_matches_oracle(bcond, semilinear):
+    N, nu, dt, K = 24, 2, 2.0 ** -6, 6
+    k, ok = pnmol.kernels.SquareExponential() + pnmol.kernels.WhiteNoise(), o.SquareExponential() + o.WhiteNoise()
+    if semilinear:
+        pde = pnmol.pde.examples.spruce_budworm_1d_discretized(dx=1.0 / (N - 1), tmax=K * dt)
+        opde = o.spruce_budworm_1d_discretized(dx=1.0 / (N - 1), tmax=K * dt)
+        cls = pnmol.sqrtform.SemiLinearLatentForceEK1
+    else:
+        kw = dict(tmax=K * dt, dx=1.0 / (N - 1), diffusion_rate=0.05, bcond=bcond)
+        pde = pnmol.pde.examples.heat_1d_discretized(kernel=pnmol.kernels.SquareExponential(), **kw)
+        opde = o.heat_1d_discretized(kernel=o.SquareExponential(), **kw)
+        cls = pnmol.sqrtform.LinearLatentForceEK1
+    solver = cls(num_derivatives=nu, steprule=pnmol.odetools.step.Constant(dt), spatial_kernel=k)
+    osolver = o.LatentForceEK1(num_derivatives=nu, steprule=o.Constant(dt), spatial_kernel=ok, semilinear=semilinear,
+                               canonical_factor_signs=True)
+    sol, osol = solver.solve(pde), osolver.solve(opde)
+    d = pde.L.shape[0]
+    # glued means and marginal stds of BOTH halves (u and eps), every derivative
+    # (the noise-free update with 1e-6 nuggets is conditioned ~1e10: two Householder QRs agree to ~1e-7 of the scale)
+    np.testing.assert_allclose(sol.mean, osol.mean, rtol=1e-5, atol=1e-6 * np.abs(osol.mean).max())
+    ovar = np.einsum("tij,tij->ti", osol.cov_sqrtm, osol.cov_sqrtm)
+    var = np.einsum("tij,tij->ti", sol.cov_sqrtm, sol.cov_sqrtm)
+    np.testing.assert_allclose(np.sqrt(var), np.sqrt(ovar), rtol=1e-4, atol=1e-6 * np.sqrt(ovar).max())
+    om, os_ = o.read_mean_and_std_latent(osol, osolver.state_iwp.projection_matrix(0))
+    assert_mean_std_parity(sol.mean[:, 0, :d], sol.marginal_std[:, 0, :d], om[:, :d], os_[:, :d])
+    np.testing.assert_allclose(sol.diffusion_squared_calibrated, osol.diffusion_squared_calibrated, rtol=1e-5)
+
+
+def test_latent_device_loop():
+    N, nu, dt, K = 24, 2, 2.0 ** -6, 5
+    kw = dict(tmax=K * dt, dx=1.0 / (N - 1), diffusion_rate=0.05, bcond="neumann", kernel=pnmol.kernels.SquareExponential())
+    pde = pnmol.pde.examples.heat_1d_discretized(**kw)
+    k = pnmol.kernels.SquareExponential() + pnmol.kernels.WhiteNoise()
+    mk = lambda: pnmol.sqrtform.LinearLatentForceEK1(num_derivatives=nu, steprule=pnmol.odetools.step.Constant(dt), spatial_kernel=k)
+    t, means, stds, sig, final = mk().solve_marginals(pde)
+    sol = mk().solve(pde)
+    np.testing.assert_allclose(means, sol.mean[:, 0, :N], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(stds[1:], sol.marginal_std[1:, 0, :N], rtol=1e-8, atol=1e-14)
