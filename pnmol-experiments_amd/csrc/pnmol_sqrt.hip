@@ -434,9 +434,7 @@ void qr_plan_free(QrPlan* pl) {
 constexpr size_t kFactorLds = sizeof(FactorLds);
 constexpr size_t kApplyLds = sizeof(double) * (CR * VLD + QB * VLD + 4 * QB * 17);
 
-int qr_configure(pnmol_ctx* ctx) {
-    static bool done = false;   // attributes are per function, per device context; cheap to repeat
-    (void)done;
+int qr_configure(pnmol_ctx* ctx) {   // attributes are per function and device; cheap to repeat
     QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_factor, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFactorLds));
     QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kApplyLds));
     return 0;
@@ -971,6 +969,8 @@ int sq_step(pnmol_sqrt_filter* f, double dt, double* norms_out) {
     if (int rc = qr_inplace(ctx, q2)) return rc;
     const int mpad = (m + 31) / 32 * 32;
     const size_t trsv_lds = sizeof(double) * (2 * (size_t)mpad + 32 * 33 + 32 + 128);
+    if (trsv_lds > 64 * 1024)   // beyond the default dynamic-LDS limit (m > ~3500: 2-D meshes); create() bounds it by 160 KB
+        QCHECK(ctx, hipFuncSetAttribute((const void*)k_sq_trsv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)trsv_lds));
     hipLaunchKernelGGL(k_sq_trsv, dim3(1), dim3(1024), trsv_lds, st, q2.W, (long)q2.ld, m, f->z, f->y, f->x, norms_out);
     hipLaunchKernelGGL(k_sq_mean_update, dim3((D + 63) / 64), dim3(256), 0, st, f->mean, f->mp, q2.W, (long)q2.ld, m,
                        f->y, m, D, kc);
