@@ -43,8 +43,7 @@ int pnmol_sqrt_update_no_meascov(pnmol_ctx* ctx, const double* H, int m, int D, 
  * predict is `propagate_cholesky_factor(A @ Cl, Ql)` (:114), the update `update_sqrt(H, Clp, E)` (:120), each one QR on
  * the device.  About 40x the flops of the covariance form behind pnmol_hip.h (which is the fast path); this is the
  * form to use when the factor itself is wanted, or when the covariance form's resolution (eps |P-|) is not enough.
- * Dense H; `estimate_error` is not evaluated (constant steps; error_sigma2 = NaN).  The filter owns ONE state, advanced
- * in place.  `pnmol_filter_desc` as in pnmol_hip.h: d_state 0 or d = white-noise model; d_state = 2d = latent-force model
+ * Dense H.  The filter owns ONE state, advanced in place.  `pnmol_filter_desc` as in pnmol_hip.h: d_state 0 or d = white-noise model; d_state = 2d = latent-force model
  * (latent.py:155-233: L = [L, I], B = [B, 0], Gamma = blockdiag(chol K, E_sqrtm), zero noise factors -> the update is
  * `update_sqrt_no_meascov`); mean buffers are then (n, 2d) glued, the factor (2D, 2D) in the stacked order. */
 typedef struct pnmol_sqrt_filter pnmol_sqrt_filter;
@@ -57,9 +56,14 @@ int pnmol_sqrt_filter_get_state(pnmol_sqrt_filter* f, double* t, double* mean_nd
 /* semilinear EK1 (white.py:189-208), as pnmol_filter_predict_mean / pnmol_filter_set_operator: M = J_x + L (d,d_state) */
 int pnmol_sqrt_filter_predict_mean(pnmol_sqrt_filter* f, double dt, double* m_at_d);
 int pnmol_sqrt_filter_set_operator(pnmol_sqrt_filter* f, const double* M_dd, const double* shift_d);
+/* `estimate_error` (white.py:153-162) in square-root form: Sq = H Ql Ql^T H^T + E E^T = Rq^T Rq, Rq the R factor of
+ * [(H Ql)^T; E^T], for the operator currently set and step size dt; kept until dt or the operator changes.  Without it
+ * a step of this dt reports error_sigma2 = NaN and a NaN error estimate (fine under the Constant rule, which discards it). */
+int pnmol_sqrt_filter_prepare_error_model(pnmol_sqrt_filter* f, double dt);
 /* one step / k steps of size dt.  info: diffusion_squared_local = |R1c^-1 z|^2 / m (white.py:125-128 with the
- * positive-diagonal factor), sigma2_whitened = z^T S^-1 z / m, error_sigma2 = NaN, info = -1 ok / 0 non-finite. */
-int pnmol_sqrt_filter_step(pnmol_sqrt_filter* f, double dt, pnmol_step_out* info);
+ * positive-diagonal factor), sigma2_whitened = z^T S^-1 z / m, error_sigma2 = z^T Sq^-1 z / m, info = -1 ok / 0
+ * non-finite.  error_estimate_d (d), optional: dt * sqrt(diag Sq) * sigma (white.py:117-129). */
+int pnmol_sqrt_filter_step(pnmol_sqrt_filter* f, double dt, pnmol_step_out* info, double* error_estimate_d);
 /* means_kd / stds_kd: (k, d_state) */
 int pnmol_sqrt_filter_steps(pnmol_sqrt_filter* f, int k, double dt, double* means_kd, double* stds_kd,
                             pnmol_step_out* info_k);

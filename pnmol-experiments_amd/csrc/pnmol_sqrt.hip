@@ -888,6 +888,15 @@ __global__ __launch_bounds__(256) void k_sq_readout(double* __restrict__ means, 
     }
 }
 
+// diag(Sq)[j] = sum_{k <= j} Rq[k][j]^2, Rq = W[0:m, 0:m] upper (white.py:160: sqrt(diag(S)))
+__global__ void k_sq_coldiag(double* __restrict__ out, const double* __restrict__ W, long ld, int m) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    double s = 0.0;
+    for (int k = 0; k <= j; ++k) s += W[(long)k * ld + j] * W[(long)k * ld + j];
+    out[j] = s;
+}
+
 }  // namespace
 
 struct pnmol_sqrt_filter {
@@ -898,7 +907,9 @@ struct pnmol_sqrt_filter {
     double *mean = nullptr, *Cl = nullptr, *T1 = nullptr, *mp = nullptr, *z = nullptr, *y = nullptr, *x = nullptr,
            *norms = nullptr;
     double t = 0.0;
-    QrPlan q1, q2;
+    QrPlan q1, q2, q3;          // q3: [(H Ql)^T; E^T] of estimate_error (white.py:153-162), factor kept in place
+    double *sqdiag = nullptr, *yq = nullptr, *xq = nullptr, *normsq = nullptr;
+    double err_dt = -1.0;        // the dt q3 holds the error model of (-1: none); reset by set_operator
     bool cl_tri = false;        // the resident factor is lower triangular: the predict QR can use the structured member lists
     std::vector<double> hB;     // boundary rows, kept for set_operator
     float last_ms = -1.f;
@@ -966,11 +977,14 @@ int sq_step(pnmol_sqrt_filter* f, double dt, double* norms_out) {
     QCHECK(ctx, hipMemcpy2DAsync(q2.W + (long)D * q2.ld, sizeof(double) * q2.ld, f->EtT, sizeof(double) * m,
                                  sizeof(double) * m, m, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(k_sq_gemv_z, dim3((m + 3) / 4), dim3(256), 0, st, f->z, f->Hraw, f->mp, f->shift, m, D, kc);
-    if (int rc = qr_inplace(ctx, q2)) return rc;
     const int mpad = (m + 31) / 32 * 32;
     const size_t trsv_lds = sizeof(double) * (2 * (size_t)mpad + 32 * 33 + 32 + 128);
     if (trsv_lds > 64 * 1024)   // beyond the default dynamic-LDS limit (m > ~3500: 2-D meshes); create() bounds it by 160 KB
         QCHECK(ctx, hipFuncSetAttribute((const void*)k_sq_trsv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)trsv_lds));
+    if (f->err_dt == dt)   // estimate_error: sigma^2 = z^T Sq^-1 z / m = |Rq^-T z|^2 / m (white.py:159)
+        hipLaunchKernelGGL(k_sq_trsv, dim3(1), dim3(1024), trsv_lds, st, f->q3.W, (long)f->q3.ld, m, f->z, f->yq, f->xq,
+                           f->normsq);
+    if (int rc = qr_inplace(ctx, q2)) return rc;
     hipLaunchKernelGGL(k_sq_trsv, dim3(1), dim3(1024), trsv_lds, st, q2.W, (long)q2.ld, m, f->z, f->y, f->x, norms_out);
     hipLaunchKernelGGL(k_sq_mean_update, dim3((D + 63) / 64), dim3(256), 0, st, f->mean, f->mp, q2.W, (long)q2.ld, m,
                        f->y, m, D, kc);
@@ -996,10 +1010,12 @@ extern "C" {
 int pnmol_sqrt_filter_destroy(pnmol_sqrt_filter* f) {
     if (!f) return -1;
     hipSetDevice(f->ctx->device);
-    for (double* p : {f->Hraw, f->shift, f->EtT, f->QlT, f->mean, f->Cl, f->T1, f->mp, f->z, f->y, f->x, f->norms})
+    for (double* p : {f->Hraw, f->shift, f->EtT, f->QlT, f->mean, f->Cl, f->T1, f->mp, f->z, f->y, f->x, f->norms,
+                      f->sqdiag, f->yq, f->xq, f->normsq})
         if (p) hipFree(p);
     qr_plan_free(&f->q1);
     qr_plan_free(&f->q2);
+    qr_plan_free(&f->q3);
     delete f;
     return 0;
 }
@@ -1051,9 +1067,11 @@ int pnmol_sqrt_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmo
         if (!alloc(&f->Hraw, (size_t)m * D) || !alloc(&f->shift, m) || !alloc(&f->EtT, (size_t)m * m) ||
             !alloc(&f->QlT, (size_t)D * D) || !alloc(&f->mean, D) || !alloc(&f->Cl, (size_t)D * D) ||
             !alloc(&f->T1, (size_t)D * D) || !alloc(&f->mp, D) || !alloc(&f->z, m) || !alloc(&f->y, m) ||
-            !alloc(&f->x, m) || !alloc(&f->norms, 2)) { rc = -4; break; }
+            !alloc(&f->x, m) || !alloc(&f->norms, 2) || !alloc(&f->sqdiag, m) || !alloc(&f->yq, m) ||
+            !alloc(&f->xq, m) || !alloc(&f->normsq, 2)) { rc = -4; break; }
         if ((rc = qr_plan_alloc(ctx, (D + QB - 1) / QB * QB + D, D, &f->q1))) { rc = -4; break; }
         if ((rc = qr_plan_alloc(ctx, D + m, m + D, &f->q2))) { rc = -4; break; }
+        if ((rc = qr_plan_alloc(ctx, D + m, m, &f->q3))) { rc = -4; break; }
         // Ql^T = (Gamma (x) Lq)^T (base/iwp.py:32-53), E^T = blockdiag(E_sqrtm, R_sqrtm)^T (white.py:184)
         std::vector<double> QlT((size_t)D * D, 0.0), EtT((size_t)m * m, 0.0);
         for (int j = 0; j < ds; ++j)
@@ -1084,6 +1102,7 @@ int pnmol_sqrt_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmo
 int pnmol_sqrt_filter_set_operator(pnmol_sqrt_filter* f, const double* M_dd, const double* shift_d) {
     if (!f || !M_dd) return -1;
     QCHECK(f->ctx, hipSetDevice(f->ctx->device));
+    f->err_dt = -1.0;
     return sq_upload_operator(f, M_dd, shift_d);
 }
 
@@ -1138,15 +1157,50 @@ int pnmol_sqrt_filter_predict_mean(pnmol_sqrt_filter* f, double dt, double* m_at
     return 0;
 }
 
-int pnmol_sqrt_filter_step(pnmol_sqrt_filter* f, double dt, pnmol_step_out* info) {
+int pnmol_sqrt_filter_prepare_error_model(pnmol_sqrt_filter* f, double dt) {
     if (!f || !(dt >= 0.0)) return -1;
     pnmol_ctx* ctx = f->ctx;
     QCHECK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int m = f->m, D = f->D;
+    const SqConst kc = sq_const(f, dt);
+    const QrPlan& q3 = f->q3;
+    // Sq = H (Ql Ql^T) H^T + E E^T (white.py:156-158) = R^T R with R of [(H Ql)^T; E^T]; (H Ql)^T = Ql^T H^T, Ql^T upper
+    QCHECK(ctx, hipMemsetAsync(q3.W, 0, sizeof(double) * (size_t)q3.Mp * q3.ld, st));
+    hipLaunchKernelGGL(k_rht, tiles(m, D), dim3(256), 0, st, q3.W, (long)q3.ld, f->QlT, (long)D, f->Hraw, D, m, kc);
+    QCHECK(ctx, hipMemcpy2DAsync(q3.W + (long)D * q3.ld, sizeof(double) * q3.ld, f->EtT, sizeof(double) * m,
+                                 sizeof(double) * m, m, hipMemcpyDeviceToDevice, st));
+    if (int rc = qr_inplace(ctx, q3)) return rc;
+    hipLaunchKernelGGL(k_sq_coldiag, dim3((m + 255) / 256), dim3(256), 0, st, f->sqdiag, q3.W, (long)q3.ld, m);
+    QCHECK(ctx, hipGetLastError());
+    f->err_dt = dt;
+    return 0;
+}
+
+int pnmol_sqrt_filter_step(pnmol_sqrt_filter* f, double dt, pnmol_step_out* info, double* error_estimate_d) {
+    if (!f || !(dt >= 0.0)) return -1;
+    pnmol_ctx* ctx = f->ctx;
+    QCHECK(ctx, hipSetDevice(ctx->device));
+    const bool have_err = f->err_dt == dt;
     if (int rc = sq_step(f, dt, f->norms)) return rc;
-    double nrm[2];
+    double nrm[2], nq[2] = {std::nan(""), std::nan("")};
     QCHECK(ctx, hipMemcpyAsync(nrm, f->norms, sizeof(nrm), hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<double> sd;
+    if (have_err) {
+        QCHECK(ctx, hipMemcpyAsync(nq, f->normsq, sizeof(nq), hipMemcpyDeviceToHost, ctx->stream));
+        if (error_estimate_d) {
+            sd.resize(f->d);
+            QCHECK(ctx, hipMemcpyAsync(sd.data(), f->sqdiag, sizeof(double) * f->d, hipMemcpyDeviceToHost, ctx->stream));
+        }
+    }
     QCHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (info) sq_fill_out(info, f->t, nrm, f->m);
+    if (info) {
+        sq_fill_out(info, f->t, nrm, f->m);
+        info->error_sigma2 = nq[0] / f->m;
+    }
+    if (error_estimate_d)   // dt * sqrt(diag Sq) * sigma, PDE rows only (white.py:117-119, :129)
+        for (int i = 0; i < f->d; ++i)
+            error_estimate_d[i] = have_err ? dt * std::sqrt(sd[i]) * std::sqrt(nq[0] / f->m) : std::nan("");
     return 0;
 }
 

@@ -89,7 +89,8 @@ SYMBOLS = {
     "pnmol_sqrt_filter_get_state": (ctypes.c_int, [_vp, _c_double_p, _c_double_p, _c_double_p]),
     "pnmol_sqrt_filter_predict_mean": (ctypes.c_int, [_vp, ctypes.c_double, _c_double_p]),
     "pnmol_sqrt_filter_set_operator": (ctypes.c_int, [_vp, _c_double_p, _c_double_p]),
-    "pnmol_sqrt_filter_step": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.POINTER(StepOut)]),
+    "pnmol_sqrt_filter_prepare_error_model": (ctypes.c_int, [_vp, ctypes.c_double]),
+    "pnmol_sqrt_filter_step": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.POINTER(StepOut), _c_double_p]),
     "pnmol_sqrt_filter_steps": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, _c_double_p, _c_double_p,
                                                ctypes.POINTER(StepOut)]),
     "pnmol_sqrt_filter_last_steps_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
@@ -421,11 +422,16 @@ class SqrtFilter:
         self.ctx.check(self.ctx.lib.pnmol_sqrt_filter_set_operator(self.handle, _dp(M), None if sh is None else _dp(sh)),
                        "pnmol_sqrt_filter_set_operator")
 
-    def step(self, dt):
+    def prepare_error_model(self, dt):
+        self.ctx.check(self.ctx.lib.pnmol_sqrt_filter_prepare_error_model(self.handle, float(dt)),
+                       "pnmol_sqrt_filter_prepare_error_model")
+
+    def step(self, dt, want_error=False):
         info = StepOut()
-        self.ctx.check(self.ctx.lib.pnmol_sqrt_filter_step(self.handle, float(dt), ctypes.byref(info)),
-                       "pnmol_sqrt_filter_step")
-        return info
+        err = np.empty(self.d) if want_error else None
+        self.ctx.check(self.ctx.lib.pnmol_sqrt_filter_step(self.handle, float(dt), ctypes.byref(info),
+                                                           _dp(err) if want_error else None), "pnmol_sqrt_filter_step")
+        return (info, err) if want_error else info
 
     def steps(self, k, dt):
         means, stds = np.empty((k, self.ds)), np.empty((k, self.ds))

@@ -4,7 +4,8 @@
 `MultivariateNormal(mean, cov_sqrtm)` by the reference's own sequence -- `propagate_cholesky_factor(A @ Cl, Ql)`, then
 `update_sqrt(H, Clp, E)` (white.py:96-146, base/sqrt.py) -- with both QRs on the device (include/pnmol_sqrt.h).  Use them
 when the factor itself is wanted or the covariance form's resolution is not enough; a step costs about 40x the
-covariance form's flops.  `estimate_error` is not evaluated: constant step rule only.  No CPU fallback.
+covariance form's flops.  `estimate_error` (white.py:153-162) is evaluated in square-root form too, when the step rule
+uses it (Adaptive).  No CPU fallback.
 """
 
 import numpy as np
@@ -20,10 +21,7 @@ class _SqrtFormMixin:
     _sqrt_filter = None
     _sqrt_last = None      # the state object whose factor is resident in the device filter
 
-    def __init__(self, *args, **kwargs):
-        super().__init__(*args, **kwargs)
-        if not isinstance(self.steprule, _step.Constant):
-            raise TypeError("the square-root form evaluates no error estimate: use the Constant step rule")
+    _err_dt = None         # the dt the device holds the error model of (linear PDE: reused until dt changes)
 
     def initialize(self, pde):
         """The reference's own initialisation (white.py:12-80), its two `update_sqrt` calls on the device: prior
@@ -53,7 +51,7 @@ class _SqrtFormMixin:
         m0 = m0_y0 - k @ z
         state = pdefilter.PDEFilterState(t=pde.t0, y=rv.MultivariateNormal(m0.reshape((n, d), order="F"), C0),
                                          error_estimate=None, reference_state=None, diffusion_squared_local=[])
-        self._sqrt_last = None
+        self._sqrt_last, self._err_dt = None, None
         return state
 
     def _stack(self, M):
@@ -72,10 +70,18 @@ class _SqrtFormMixin:
             m_at = flt.predict_mean(dt)
             M, shift = self._linearize(pde, m_at, state.t + dt)
             flt.set_operator(self._stack(M), shift)
-        info = flt.step(dt)
+            self._err_dt = None
+        error = None
+        if self._wants_error:
+            if self._err_dt != dt:                 # estimate_error's Sq depends on (operator, dt) only (white.py:153-162)
+                flt.prepare_error_model(dt)
+                self._err_dt = dt
+            info, error = flt.step(dt, want_error=True)
+        else:
+            info = flt.step(dt)
         self.last_step_info = info
         _, mean, C = flt.get_state()
-        new = pdefilter.PDEFilterState(t=state.t + dt, y=rv.MultivariateNormal(mean, C), error_estimate=None,
+        new = pdefilter.PDEFilterState(t=state.t + dt, y=rv.MultivariateNormal(mean, C), error_estimate=error,
                                        reference_state=self._reference_state(mean), diffusion_squared_local=info.diffusion_squared_local)
         self._sqrt_last = new
         return new, dict(num_f_evaluations=1, num_df_evaluations=1)
@@ -83,6 +89,10 @@ class _SqrtFormMixin:
     @staticmethod
     def _reference_state(mean):
         return np.abs(mean[0])                     # white.py:141
+
+    @property
+    def _wants_error(self):
+        return not isinstance(self.steprule, _step.Constant)   # Constant discards it (odetools/step.py:49-52)
 
     def solve_marginals(self, pde, *, num_steps=None):
         """As `pnmol.white.LinearWhiteNoiseEK1.solve_marginals`, the loop kept on the device in square-root form."""
@@ -133,6 +143,8 @@ class _SqrtFormLatentMixin(_SqrtFormMixin):
     @staticmethod
     def _reference_state(mean):
         return None                                # latent.py:224
+
+    _wants_error = False                           # no error estimate in this model (latent.py:224)
 
     def initialize(self, pde):
         """The reference's own initialisation (latent.py:20-134), its two `update_sqrt` calls (nuggets 1e-6) on the device."""

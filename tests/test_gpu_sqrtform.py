@@ -152,3 +152,38 @@ def test_latent_device_loop():
     sol = mk().solve(pde)
     np.testing.assert_allclose(means, sol.mean[:, 0, :N], rtol=1e-10, atol=1e-13)
     np.testing.assert_allclose(stds[1:], sol.marginal_std[1:, 0, :N], rtol=1e-8, atol=1e-14)
+
+
+# ---- estimate_error in square-root form: the Adaptive rule (odetools/step.py:58-119) ---------------------------------
+@pytest.mark.parametrize("semilinear", [False, True])
+def test_adaptive_steps_follow_the_oracle(semilinear):
+    kw = dict(abstol=1e-3, reltol=1e-2)
+    k, ok = pnmol.kernels.SquareExponential() + pnmol.kernels.WhiteNoise(), o.SquareExponential() + o.WhiteNoise()
+    if semilinear:
+        pkw = dict(tmax=0.4, dx=1.0 / 11, diffusion_rate=0.05, bcond="neumann")
+        pde = pnmol.pde.examples.spruce_budworm_1d_discretized(kernel=pnmol.kernels.SquareExponential(), **pkw)
+        opde = o.spruce_budworm_1d_discretized(kernel=o.SquareExponential(), **pkw)
+        cls = pnmol.sqrtform.SemiLinearWhiteNoiseEK1
+    else:
+        pkw = dict(tmax=0.4, dx=1.0 / 11, diffusion_rate=0.05, bcond="neumann")
+        pde = pnmol.pde.examples.heat_1d_discretized(kernel=pnmol.kernels.SquareExponential(), **pkw)
+        opde = o.heat_1d_discretized(kernel=o.SquareExponential(), **pkw)
+        cls = pnmol.sqrtform.LinearWhiteNoiseEK1
+    solver = cls(num_derivatives=2, spatial_kernel=k, steprule=pnmol.odetools.step.Adaptive(**kw))
+    osolver = o.WhiteNoiseEK1(num_derivatives=2, spatial_kernel=ok, semilinear=semilinear, canonical_factor_signs=True,
+                              steprule=o.Adaptive(**kw))
+    sol, osol = solver.solve(pde), osolver.solve(opde)
+    assert sol.info == osol.info and sol.info["num_attempted_steps"] >= sol.info["num_steps"] > 3
+    np.testing.assert_allclose(sol.t, osol.t, rtol=1e-9)
+    np.testing.assert_allclose(sol.mean[:, 0], osol.mean[:, 0], rtol=1e-6, atol=1e-8 * np.abs(osol.mean).max())
+
+
+def test_error_estimate_matches_oracle():
+    N, nu, dt = 40, 2, 2.0 ** -6
+    pde, _, opde, osolver = make_pair(N, nu, dt, 2, bcond="dirichlet")
+    solver = pnmol.sqrtform.LinearWhiteNoiseEK1(num_derivatives=nu, steprule=pnmol.odetools.step.Adaptive(),
+                                                spatial_kernel=pnmol.kernels.Matern52() + pnmol.kernels.WhiteNoise())
+    s, os_ = solver.initialize(pde), osolver.initialize(opde)
+    new, _ = solver.attempt_step(s, dt, pde)
+    onew, _ = osolver.attempt_step(os_, dt, opde)
+    np.testing.assert_allclose(new.error_estimate, onew.error_estimate, rtol=1e-6)
