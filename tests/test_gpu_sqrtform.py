@@ -22,7 +22,8 @@ def _sqrt_solver(nu, dt, semilinear=False, kernel=None):
                spatial_kernel=kernel or pnmol.kernels.Matern52() + pnmol.kernels.WhiteNoise())
 
 
-@pytest.mark.parametrize("N,nu,bcond", [(32, 2, "dirichlet"), (32, 1, "neumann"), (50, 3, "neumann"), (128, 2, "dirichlet")])
+@pytest.mark.parametrize("N,nu,bcond", [(32, 2, "dirichlet"), (32, 1, "neumann"), (50, 3, "neumann"), (128, 2, "dirichlet"),
+                                        (512, 2, "neumann")])   # the headline size: three tree levels in the update QR
 def test_single_step_from_the_oracles_state(N, nu, bcond):
     """One attempt_step from the oracle's own initial state: mean, factor, sigma^2."""
     dt = 2.0 ** -7
