@@ -44,10 +44,11 @@ constexpr int VLD = 33;           // LDS row stride of V in k_qr_apply (bank-con
         }                                                                                  \
     } while (0)
 
+constexpr int FLD = QB + 1;   // LDS row stride of the chunk in k_qr_factor
+
 struct FactorLds {
-    double A[CR * QB];      // V (unit lower trapezoidal), for the Gram product and the workspace copy
+    double A[CR * FLD];     // the chunk's panel columns (staging of the coalesced load), later V (unit lower trapezoidal)
     double R[QB * QB];      // rows of R as they are finished
-    double red[FAN * QB];   // per-wave partial inner products
     double G[QB * QB];      // V^T V
     double tau[QB], scale[QB];
     double col[2][CR];      // column J of the working matrix (ping-pong by step parity)
@@ -67,29 +68,38 @@ __device__ __forceinline__ int member_rb(const MemberMap& mm, int p, int s, int 
     return idx < mm.ntop ? p + idx : mm.bot0 + (idx - mm.ntop);
 }
 
-// Householder QR of one chunk's panel (CR x 32, in LDS).  Column step J, with the inner products of column J against all
-// columns k >= J taken in one pass (s_k = sum_{i>J} A[i][J] A[i][k]; k = J gives the dlarfg sigma), so a step costs two
-// block barriers.  Nothing is updated in place that another thread still reads in the same phase: row J of R goes to
-// L.R, the reflector stays unscaled in A's column J (scale[J] applied at the end).
+// x + (x rotated right by N lanes within its row of 16 lanes): after N = 8, 4, 2, 1 every lane holds the row's sum
+template <int N>
+__device__ __forceinline__ double row_ror_add(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x120 + N, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x120 + N, 0xf, 0xf, false);
+    return x + __hiloint2double(hi, lo);
+}
+
+// Householder QR of one chunk's panel (CR x 32).  Thread (k, g) = (t >> 4, t & 15) keeps rows g, g+16, ... of column k in
+// registers, so the 16 row groups of a column sit in ONE wave: the inner products of column J with the wave's own four
+// columns (and with itself: the dlarfg sigma, formed redundantly by every wave) are reduced over 16 lanes by shuffles --
+// no LDS, no barrier.  What crosses waves is column J and row J of the current matrix (L.col, L.rowb, ping-pong by step
+// parity, published by their owners at the end of the step before): ONE block barrier per column.  Row J of R goes to
+// L.R; the reflector stays unscaled in the registers (scale[J] applied at the end).  Rows beyond the chunk's members are
+// zero on input and stay zero.
 __global__ __launch_bounds__(FT) void k_qr_factor(double* __restrict__ W, long ld, MemberMap mm, int p, int s,
                                                   double* __restrict__ Vws, double* __restrict__ Tws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char qr_lds_raw[];
     FactorLds& L = *reinterpret_cast<FactorLds*>(qr_lds_raw);
-    const int c = blockIdx.x, t = threadIdx.x, k = t & 31, g = t >> 5, w = t >> 6, lane = t & 63;
+    const int c = blockIdx.x, t = threadIdx.x, k = t >> 4, g = t & 15, w = t >> 6, lane = t & 63;
     int nm = 0;
     for (int q = 0; q < FAN; ++q) nm += member_rb(mm, p, s, c, q) >= 0;
     if (nm == 0 || (nm == 1 && s > 1)) return;  // a lone survivor is already triangular (k_qr_apply skips it too)
-    const int rows = nm * QB;
 
-    // the thread's 16 entries of column k stay in registers; what the others need of the current step -- column J and
-    // row J -- goes through the double-buffered L.col / L.rowb, published at the end of the step before
+    for (int e = t; e < CR * QB; e += FT) {   // coalesced: 32 consecutive columns of one row
+        const int i = e >> 5, kk = e & 31, q = i >> 5;
+        L.A[i * FLD + kk] = (q < nm) ? W[((long)member_rb(mm, p, s, c, q) * QB + (i & 31)) * ld + (long)p * QB + kk] : 0.0;
+    }
+    __syncthreads();
     double a[RPT];
 #pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-        const int i = g + NG * r;
-        const int q = i >> 5;
-        a[r] = (q < nm) ? W[((long)member_rb(mm, p, s, c, q) * QB + (i & 31)) * ld + (long)p * QB + k] : 0.0;
-    }
+    for (int r = 0; r < RPT; ++r) a[r] = L.A[(g + NG * r) * FLD + k];
     if (k == 0) {
 #pragma unroll
         for (int r = 0; r < RPT; ++r) L.col[0][g + NG * r] = a[r];
@@ -101,25 +111,24 @@ __global__ __launch_bounds__(FT) void k_qr_factor(double* __restrict__ W, long l
     for (int J = 0; J < QB; ++J) {
         const int cur = J & 1;
         double vi[RPT];
-        double part = 0.0;
+        double pk[4] = {0, 0, 0, 0}, pJ[4] = {0, 0, 0, 0};   // four independent accumulation chains each
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) {
-            const int i = g + NG * r;
-            vi[r] = (i > J && i < rows) ? L.col[cur][i] : 0.0;
-            part += vi[r] * a[r];
+        for (int r = 0; r < RPT; ++r) {   // rows i = g + 16 r > J of column J (r and J are compile-time after unrolling)
+            if (NG * r + NG - 1 <= J) {
+                vi[r] = 0.0;
+            } else {
+                const double v = L.col[cur][g + NG * r];
+                vi[r] = (NG * r > J || g + NG * r > J) ? v : 0.0;
+                pk[r & 3] += vi[r] * a[r];
+                pJ[r & 3] += vi[r] * vi[r];
+            }
         }
-        part += __shfl_xor(part, 32);  // the wave's two row groups
-        if (lane < 32) L.red[w * QB + k] = part;
-        __syncthreads();
-        double rk[FAN], rJ[FAN];
-#pragma unroll
-        for (int ww = 0; ww < FAN; ++ww) {
-            rk[ww] = L.red[ww * QB + k];
-            rJ[ww] = L.red[ww * QB + J];
-        }
-        static_assert(FAN == 8, "pairwise sums below are written for 8 partials");
-        const double sk = ((rk[0] + rk[1]) + (rk[2] + rk[3])) + ((rk[4] + rk[5]) + (rk[6] + rk[7]));
-        const double sJ = ((rJ[0] + rJ[1]) + (rJ[2] + rJ[3])) + ((rJ[4] + rJ[5]) + (rJ[6] + rJ[7]));
+        double sk = (pk[0] + pk[1]) + (pk[2] + pk[3]), sJ = (pJ[0] + pJ[1]) + (pJ[2] + pJ[3]);
+        // over the column's 16 row groups = one DPP row of the wave
+        sk = row_ror_add<8>(sk), sJ = row_ror_add<8>(sJ);
+        sk = row_ror_add<4>(sk), sJ = row_ror_add<4>(sJ);
+        sk = row_ror_add<2>(sk), sJ = row_ror_add<2>(sJ);
+        sk = row_ror_add<1>(sk), sJ = row_ror_add<1>(sJ);
         // dlarfg: H = I - tau v v^T, v = [1; x / (alpha - beta)], beta = -sign(alpha) |(alpha, x)|; with
         // nrm = |(alpha, x)|: tau = (beta - alpha) / beta = 1 + |alpha| / nrm, 1 / (alpha - beta) = sign(alpha) / (|alpha| + nrm)
         // -- one rsqrt and one reciprocal on the step's critical path instead of a sqrt and two divisions
@@ -149,12 +158,15 @@ __global__ __launch_bounds__(FT) void k_qr_factor(double* __restrict__ W, long l
         if (k > J) {
             const double fs = f * scale;
 #pragma unroll
-            for (int r = 0; r < RPT; ++r) a[r] -= fs * vi[r];   // vi = 0 outside the reflector's rows
+            for (int r = 0; r < RPT; ++r)
+                if (NG * r + NG - 1 > J) a[r] -= fs * vi[r];
         }
         if (J + 1 < QB) {
-            if (k == J + 1) {
+            if (w == (J + 1) >> 2) {        // the wave that owns column J+1
+                if (k == J + 1) {
 #pragma unroll
-                for (int r = 0; r < RPT; ++r) L.col[cur ^ 1][g + NG * r] = a[r];
+                    for (int r = 0; r < RPT; ++r) L.col[cur ^ 1][g + NG * r] = a[r];
+                }
             }
             if (g == (J + 1) % NG) L.rowb[cur ^ 1][k] = a[(J + 1) / NG];
         }
@@ -167,7 +179,7 @@ __global__ __launch_bounds__(FT) void k_qr_factor(double* __restrict__ W, long l
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
             const int i = g + NG * r;
-            L.A[i * QB + k] = (i > k && i < rows) ? a[r] * sc : (i == k ? 1.0 : 0.0);
+            L.A[i * FLD + k] = (i > k) ? a[r] * sc : (i == k ? 1.0 : 0.0);
         }
     }
     __syncthreads();
@@ -176,9 +188,9 @@ __global__ __launch_bounds__(FT) void k_qr_factor(double* __restrict__ W, long l
         const int fr = lane & 15, fk = lane >> 4, jt = w >> 1, ct = w & 1;
         d4 acc = {0, 0, 0, 0};
         for (int st = 0; st < CR / 4; ++st) {
-            const double a = L.A[(4 * st + fk) * QB + jt * 16 + fr];
-            const double b = L.A[(4 * st + fk) * QB + ct * 16 + fr];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            const double va = L.A[(4 * st + fk) * FLD + jt * 16 + fr];
+            const double vb = L.A[(4 * st + fk) * FLD + ct * 16 + fr];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va, vb, acc, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) L.G[(jt * 16 + fk + 4 * r) * QB + ct * 16 + fr] = acc[r];
@@ -199,16 +211,11 @@ __global__ __launch_bounds__(FT) void k_qr_factor(double* __restrict__ W, long l
 #pragma unroll
         for (int J = 0; J < QB; ++J) Tg[t * QB + J] = trow[J];
     }
-    // V to the workspace, R (upper, zero below) to the first member
+    // V to the workspace, R (upper, zero below) to the first member: coalesced from LDS
     double* Vg = Vws + (long)c * CR * QB;
-    for (int r = 0; r < RPT; ++r) {
-        const int i = g + NG * r;
-        Vg[i * QB + k] = L.A[i * QB + k];
-    }
-    if (g < 2) {
-        for (int r = g; r < QB; r += 2)
-            W[((long)member_rb(mm, p, s, c, 0) * QB + r) * ld + (long)p * QB + k] = L.R[r * QB + k];
-    }
+    for (int e = t; e < CR * QB; e += FT) Vg[e] = L.A[(e >> 5) * FLD + (e & 31)];
+    for (int e = t; e < QB * QB; e += FT)
+        W[((long)member_rb(mm, p, s, c, 0) * QB + (e >> 5)) * ld + (long)p * QB + (e & 31)] = L.R[e];
 }
 
 // C <- (I - V T V^T)^T C = C - V (T^T (V^T C)) on the chunk's rows of 64 trailing columns per block, 16 per wave.  The
