@@ -188,3 +188,19 @@ def test_error_estimate_matches_oracle():
     new, _ = solver.attempt_step(s, dt, pde)
     onew, _ = osolver.attempt_step(os_, dt, opde)
     np.testing.assert_allclose(new.error_estimate, onew.error_estimate, rtol=1e-6)
+
+
+# ---- at BASELINE's full size: two independent device algorithms for the same step ------------------------------------
+def test_full_size_covariance_form_agrees_with_square_root_form():
+    """N=512, nu=2, dt=2^-7 (BASELINE config 1), 25 steps: the covariance form (Cholesky sweep + down-date, the bench
+    path) against the square-root form (two Householder QRs per step).  They share the problem assembly and nothing
+    else; agreement at the north-star tolerances is a full-size check no CPU oracle run is needed for."""
+    N, nu, dt, K = 512, 2, 2.0 ** -7, 25
+    pde, cov_solver, _, _ = make_pair(N, nu, dt, K)
+    t, mq, sq, sigq, _ = _sqrt_solver(nu, dt).solve_marginals(pde)
+    tc, mc, sc, sigc, _ = cov_solver.solve_marginals(pde)
+    assert np.array_equal(t, tc) and len(t) == K + 1
+    assert np.isfinite(mq).all() and np.isfinite(sq).all()
+    assert_mean_std_parity(mc, sc, mq, sq)
+    np.testing.assert_allclose(mc, mq, rtol=1e-8, atol=1e-10 * np.abs(mq).max())      # means agree far below the bar
+    np.testing.assert_allclose(sigc, sigq, rtol=1e-6)
