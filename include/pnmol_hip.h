@@ -90,6 +90,9 @@ int pnmol_state_destroy(pnmol_state* s);
 int pnmol_state_clone(const pnmol_state* s, pnmol_state** out); /* reject/retry, pdefilter.py:192-223 */
 /* upload `PDEFilterState(t, y=(mean, cov))`; cov = cov_sqrtm @ cov_sqrtm.T (base/rv.py:12-14) */
 int pnmol_state_set(pnmol_state* s, double t, const double* mean_nd, const double* cov_DD);
+/* the same from a square root: any C (D,D) with C C^T = cov, e.g. the reference's `cov_sqrtm`; C C^T is formed on the
+ * device (no O(D^3) host work).  Used by `initialize` (white.py:12-80), whose factor comes from `pnmol_sqrt_update`. */
+int pnmol_state_set_sqrtm(pnmol_state* s, double t, const double* mean_nd, const double* cov_sqrtm_DD);
 int pnmol_state_get_time(const pnmol_state* s, double* t);
 int pnmol_state_get_mean(const pnmol_state* s, double* mean_nd);       /* (n,d)            */
 int pnmol_state_get_cov(const pnmol_state* s, double* cov_DD);         /* (D,D) F-order    */

@@ -2407,6 +2407,75 @@ int pnmol_state_set(pnmol_state* s, double t, const double* mean_nd, const doubl
     return 0;
 }
 
+namespace {
+// P = C C^T written straight into the state's derivative-major padded layout, C (D x D, any square root) in the
+// reference's F-flattened order: P[(a dp + j)(Dp) + (b dp + k)] = sum_c C[j n + a][c] C[k n + b][c].  One 32x32 tile of
+// points (j, k) for one derivative pair (a, b) per block, on the MFMA; also the marginal variances.
+__global__ __launch_bounds__(256) void k_cct_layout(double* __restrict__ P, double* __restrict__ var,
+                                                    const double* __restrict__ C, int d, int n, int dp, long Dp) {
+    __shared__ double sA[32][33], sB[32][33];
+    const int t = threadIdx.x, w = t >> 6, lane = t & 63, fr = lane & 15, fk = lane >> 4, wr = w >> 1, wc = w & 1;
+    const int tx = t & 31, ty = t >> 5;
+    const int a = blockIdx.z / n, b = blockIdx.z % n, j0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+    const long D = (long)n * d;
+    d4 acc = {0, 0, 0, 0};
+    for (long c0 = 0; c0 < D; c0 += 32) {
+        for (int r = ty; r < 32; r += 8) {
+            const int j = j0 + r, k = k0 + r;
+            const long c = c0 + tx;
+            sA[r][tx] = (j < d && c < D) ? C[((long)j * n + a) * D + c] : 0.0;
+            sB[r][tx] = (k < d && c < D) ? C[((long)k * n + b) * D + c] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < 8; ++st)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[wr * 16 + fr][4 * st + fk], sB[wc * 16 + fr][4 * st + fk], acc, 0, 0, 0);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int j = j0 + wr * 16 + fk + 4 * r, k = k0 + wc * 16 + fr;
+        if (j < d && k < d) {
+            P[((long)a * dp + j) * Dp + (long)b * dp + k] = acc[r];
+            if (a == b && j == k) var[(long)a * dp + j] = acc[r];
+        }
+    }
+}
+}  // namespace
+
+int pnmol_state_set_sqrtm(pnmol_state* s, double t, const double* mean_nd, const double* cov_sqrtm_DD) {
+    if (!s || !mean_nd || !cov_sqrtm_DD) return -1;
+    pnmol_filter* f = s->f;
+    pnmol_ctx* ctx = f->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int n = f->n, d = f->ds, dp = f->dp;
+    const long D = (long)n * d, Dp = f->Dp;
+    std::vector<double> hm((size_t)Dp, 0.0);
+    for (int a = 0; a < n; ++a)
+        for (int j = 0; j < d; ++j) hm[(size_t)a * dp + j] = mean_nd[(size_t)a * d + j];
+    double* dC = nullptr;
+    if (hipMalloc(&dC, sizeof(double) * (size_t)D * D) != hipSuccess) return -4;
+    int rc = 0;
+    do {
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = -2; break; }
+        if (hipMemcpy(s->mean, hm.data(), sizeof(double) * hm.size(), hipMemcpyHostToDevice) != hipSuccess) { rc = -2; break; }
+        if (hipMemcpy(dC, cov_sqrtm_DD, sizeof(double) * (size_t)D * D, hipMemcpyHostToDevice) != hipSuccess) { rc = -2; break; }
+        if (hipMemsetAsync(s->P, 0, sizeof(double) * (size_t)Dp * Dp, ctx->stream) != hipSuccess) { rc = -2; break; }
+        if (hipMemsetAsync(s->var, 0, sizeof(double) * (size_t)Dp, ctx->stream) != hipSuccess) { rc = -2; break; }
+        hipLaunchKernelGGL(k_cct_layout, dim3((d + 31) / 32, (d + 31) / 32, n * n), dim3(256), 0, ctx->stream, s->P, s->var,
+                           dC, d, n, dp, Dp);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = -2; break; }
+    } while (0);
+    hipFree(dC);
+    if (rc) {
+        ctx->err = std::string("pnmol_state_set_sqrtm: ") + hipGetErrorString(hipGetLastError());
+        return rc;
+    }
+    s->t = t;
+    s->frame_dt = 0.0;
+    return 0;
+}
+
 int pnmol_state_get_time(const pnmol_state* s, double* t) {
     if (!s || !t) return -1;
     *t = s->t;

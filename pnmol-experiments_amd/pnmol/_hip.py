@@ -61,6 +61,7 @@ SYMBOLS = {
     "pnmol_state_destroy": (ctypes.c_int, [_vp]),
     "pnmol_state_clone": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
     "pnmol_state_set": (ctypes.c_int, [_vp, ctypes.c_double, _c_double_p, _c_double_p]),
+    "pnmol_state_set_sqrtm": (ctypes.c_int, [_vp, ctypes.c_double, _c_double_p, _c_double_p]),
     "pnmol_state_get_time": (ctypes.c_int, [_vp, _c_double_p]),
     "pnmol_state_get_mean": (ctypes.c_int, [_vp, _c_double_p]),
     "pnmol_state_get_cov_sqrtm": (ctypes.c_int, [_vp, _c_double_p]),
@@ -338,6 +339,13 @@ class State:
         D = f.n * f.ds
         a, b = _f64(mean_nd, (f.n, f.ds)), _f64(cov_DD, (D, D))
         self.ctx.check(self.lib.pnmol_state_set(self.handle, float(t), _dp(a), _dp(b)), "pnmol_state_set")
+
+    def set_sqrtm(self, t, mean_nd, cov_sqrtm_DD):
+        """As `set`, from any square root C of the covariance; C C^T is formed on the device."""
+        f = self.filter
+        D = f.n * f.ds
+        a, b = _f64(mean_nd, (f.n, f.ds)), _f64(cov_sqrtm_DD, (D, D))
+        self.ctx.check(self.lib.pnmol_state_set_sqrtm(self.handle, float(t), _dp(a), _dp(b)), "pnmol_state_set_sqrtm")
 
     @property
     def t(self):

@@ -13,6 +13,8 @@ Documented deviations from the reference's numbers:
     z^T S^-1 z / m.
 """
 
+import os
+
 import numpy as np
 import scipy.linalg
 import scipy.sparse
@@ -48,6 +50,34 @@ class _WhiteNoiseEK1Base(pdefilter.PDEFilter):
         self._gram = gamma @ gamma.T
         self._error_models = {}
 
+    # True: the reference's own two `update_sqrt` calls, on the device (below); False: closed form on the host
+    initialize_on_device = os.environ.get("PNMOL_INIT_ON_DEVICE", "0") == "1"
+
+    def _initialize_on_device(self, pde, gamma):
+        """white.py:12-80 as written: prior kron(Gamma, c I) -> update_sqrt on y0 (nugget 1e-10) -> update_sqrt on the
+        PDE/BC residual at t0, both QRs on the device (include/pnmol_sqrt.h); the factor goes to the device state, which
+        forms C C^T itself (`pnmol_state_set_sqrtm`).  No O(d^3) host work."""
+        from .base import sqrt as dsqrt
+
+        ctx = self._device_filter.ctx
+        n, d, nB = self.num_derivatives + 1, pde.L.shape[0], pde.B.shape[0]
+        C0_raw = np.kron(gamma, self.diffuse_prior_scale * np.eye(n))
+        C0_y0, k_y0, _ = dsqrt.update_sqrt(self.E0, C0_raw, 1e-10 * np.eye(d), ctx=ctx)
+        m0_y0 = k_y0 @ pde.y0
+        M, shift = self._linearize(pde, m0_y0[0::n], pde.t0)
+        H = np.zeros((d + nB, n * d))
+        H[:d, 0::n] = -M
+        H[np.arange(d), np.arange(d) * n + 1] += 1.0
+        H[d:, 0::n] = pde.B
+        z = H @ m0_y0 + np.concatenate([shift, np.zeros(nB)])
+        E = np.zeros((d + nB, d + nB))
+        E[:d, :d], E[d:, d:] = pde.E_sqrtm, pde.R_sqrtm
+        C0, k, _ = dsqrt.update_sqrt(H, C0_y0, E + 1e-10 * np.eye(d + nB), ctx=ctx)
+        mean = (m0_y0 - k @ z).reshape((n, d), order="F")
+        dev = self._device_filter.new_state()
+        dev.set_sqrtm(pde.t0, mean, C0)
+        return mean, dev
+
     def initialize(self, pde):
         """Initial state: prior conditioned on y0 and on the PDE/BC residual at t0 (white.py:12-80).
 
@@ -59,6 +89,10 @@ class _WhiteNoiseEK1Base(pdefilter.PDEFilter):
         self.iwp, self.E0, self.E1, gamma = self.initialize_iwp(pde)
         self._bind(pde, gamma)
         n, d = self.num_derivatives + 1, pde.L.shape[0]
+        if self.initialize_on_device:
+            mean, dev = self._initialize_on_device(pde, gamma)
+            return pdefilter.PDEFilterState(t=pde.t0, y=rv.DeviceMultivariateNormal(mean, dev), error_estimate=None,
+                                            reference_state=None, diffusion_squared_local=[])
         mean, blocks = self._initial_moments(pde)
         cov = np.zeros((n * d, n * d))
         for (a, b), blk in blocks.items():

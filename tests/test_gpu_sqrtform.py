@@ -204,3 +204,26 @@ def test_full_size_covariance_form_agrees_with_square_root_form():
     assert_mean_std_parity(mc, sc, mq, sq)
     np.testing.assert_allclose(mc, mq, rtol=1e-8, atol=1e-10 * np.abs(mq).max())      # means agree far below the bar
     np.testing.assert_allclose(sigc, sigq, rtol=1e-6)
+
+
+# ---- the reference's initialisation on the device, for the covariance-form solvers (white.initialize_on_device) -------
+@pytest.mark.parametrize("N,nu,bcond", [(32, 2, "dirichlet"), (40, 1, "neumann"), (128, 2, "dirichlet")])
+def test_device_initialisation_matches_oracle_and_host(N, nu, bcond):
+    dt = 2.0 ** -7
+    pde, solver, opde, osolver = make_pair(N, nu, dt, 4, bcond=bcond)
+    host = solver.initialize(pde)
+    solver.initialize_on_device = True
+    dev = solver.initialize(pde)
+    ost = osolver.initialize(opde)
+    ocov = ost.y.cov_sqrtm @ ost.y.cov_sqrtm.T
+    scale = np.sqrt(np.abs(np.diag(ocov)).max())
+    for st in (dev, host):
+        np.testing.assert_allclose(st.y.mean, ost.y.mean, rtol=1e-7, atol=1e-9 * np.abs(ost.y.mean).max())
+        cov = st.y.cov
+        sd = np.maximum(np.sqrt(np.abs(np.diag(ocov))), 1e-8 * scale)
+        assert np.max(np.abs(cov - ocov) / np.outer(sd, sd)) < 1e-5
+    # and the solve that starts from it
+    sol = solver.solve(pde)
+    osol = osolver.solve(opde)
+    om, os_ = o.read_mean_and_std(osol, osolver.E0)
+    assert_mean_std_parity(sol.mean[:, 0], sol.marginal_std[:, 0], om, os_)
