@@ -16,6 +16,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -450,10 +451,23 @@ int qr_configure(pnmol_ctx* ctx) {   // attributes are per function and device; 
 // R factor of the padded work matrix, in place (upper triangle of W's leading ld x ld block).  tri_bot0 > 0: the matrix
 // is two stacked blocks, rows [0, 32 tri_bot0) and from row block tri_bot0 on, the upper one upper triangular up to
 // `bulge` < 32 rows below its diagonal, the lower one upper triangular: panel p then only touches the member list above.
-int qr_inplace(pnmol_ctx* ctx, const QrPlan& pl, int tri_bot0 = 0) {
+// stacked_tri > 0: a dense block of `stacked_tri` row blocks on top of an upper TRIANGULAR block (the one-QR step below):
+// panel p has the dense rows from its diagonal on and the triangle's row blocks 0..p; once the dense rows are used up
+// (p >= stacked_tri) the diagonal block is in the triangle, whose blocks p - stacked_tri .. p carry the panel.
+int qr_inplace(pnmol_ctx* ctx, const QrPlan& pl, int tri_bot0 = 0, int stacked_tri = 0) {
     for (int p = 0; p < pl.ncb; ++p) {
         MemberMap mm;
-        if (tri_bot0 > 0) {
+        if (stacked_tri > 0) {
+            const int nbot = pl.nrb - stacked_tri;
+            if (p < stacked_tri) {
+                mm.ntop = stacked_tri - p;
+                mm.bot0 = stacked_tri;
+                mm.cnt = mm.ntop + std::min(p + 1, nbot);
+            } else {
+                mm.ntop = mm.cnt = std::min(p, nbot - 1) - (p - stacked_tri) + 1;
+                mm.bot0 = 0;
+            }
+        } else if (tri_bot0 > 0) {
             mm.ntop = std::min(2, tri_bot0 - p);
             mm.bot0 = tri_bot0;
             mm.cnt = mm.ntop + std::min(p + 1, pl.nrb - tri_bot0);
@@ -725,6 +739,40 @@ __global__ void k_sq_fill_r(double* __restrict__ W2, long ld2, int c0, const dou
     W2[(long)i * ld2 + c0 + k] = (k >= i) ? R[(long)i * ldr + k] : 0.0;
 }
 
+// out[i][j] = sum_k T1[k][i] Hraw[j][k] p[k % n]  (= (H T1)^T, H = Hraw P, T1 = A Pinv Cl lower triangular up to the n x n
+// point blocks when Cl is (`tri`): T1[k][i] = 0 for i >= k + n, so k starts a tile before i0): 32x32 tile per block
+__global__ __launch_bounds__(256) void k_sq_tht(double* __restrict__ out, long ldo, const double* __restrict__ T1,
+                                                const double* __restrict__ Hraw, int D, int m, SqConst kc, int tri) {
+    __shared__ double sA[32][33], sH[32][33];
+    const int t = threadIdx.x, w = t >> 6, lane = t & 63, fr = lane & 15, fk = lane >> 4, wr = w >> 1, wc = w & 1;
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32, tx = t & 31, ty = t >> 5;
+    d4 acc = {0, 0, 0, 0};
+    for (int k0 = (tri && i0 >= 32) ? i0 - 32 : 0; k0 < D; k0 += 32) {
+        for (int r = ty; r < 32; r += 8) {
+            const int k = k0 + r, i = i0 + tx, j = j0 + r, kh = k0 + tx;
+            sA[r][tx] = (k < D && i < D) ? T1[(long)k * D + i] : 0.0;                          // sA[k][i]
+            sH[r][tx] = (j < m && kh < D) ? Hraw[(long)j * D + kh] * kc.p[kh % kc.n] : 0.0;   // sH[j][k]
+        }
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < 8; ++st)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[4 * st + fk][wr * 16 + fr], sH[wc * 16 + fr][4 * st + fk], acc, 0, 0, 0);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + wr * 16 + fk + 4 * r, j = j0 + wc * 16 + fr;
+        if (i < D && j < m) out[(long)i * ldo + j] = acc[r];
+    }
+}
+
+// dst[i][c] = src[i][c] for c >= i, 0 below the diagonal (what a finished QR leaves below R is not R)
+__global__ void k_sq_copy_upper(double* __restrict__ dst, long ldd, const double* __restrict__ src, long lds, int n) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y * blockDim.y + threadIdx.y;
+    if (c >= n || i >= n) return;
+    dst[(long)i * ldd + c] = (c >= i) ? src[(long)i * lds + c] : 0.0;
+}
+
 // z = Hraw P mp + shift (white.py:169-186): one wave per row
 __global__ __launch_bounds__(256) void k_sq_gemv_z(double* __restrict__ z, const double* __restrict__ Hraw,
                                                    const double* __restrict__ mp, const double* __restrict__ shift,
@@ -914,6 +962,10 @@ struct pnmol_sqrt_filter {
     double *mean = nullptr, *Cl = nullptr, *T1 = nullptr, *mp = nullptr, *z = nullptr, *y = nullptr, *x = nullptr,
            *norms = nullptr;
     double t = 0.0;
+    QrPlan q4;                  // one-QR step: [[T1^T H^T, T1^T], [Rc]] (see sq_step)
+    double* Rc = nullptr;        // R of the step-invariant rows [[Ql^T H^T, Ql^T], [E^T, 0]] for (rc_dt, rc_op)
+    double rc_dt = -1.0, prev_dt = -1.0;
+    long opver = 0, rc_op = -1, prev_op = -1;
     QrPlan q1, q2, q3;          // q3: [(H Ql)^T; E^T] of estimate_error (white.py:153-162), factor kept in place
     double *sqdiag = nullptr, *yq = nullptr, *xq = nullptr, *normsq = nullptr;
     double err_dt = -1.0;        // the dt q3 holds the error model of (-1: none); reset by set_operator
@@ -954,6 +1006,7 @@ int sq_upload_operator(pnmol_sqrt_filter* f, const double* M, const double* shif
     for (int i = 0; i < nB; ++i)
         for (int j = 0; j < ds; ++j) H[(size_t)(d + i) * D + (size_t)j * n] = f->hB[(size_t)i * ds + j];
     pnmol_ctx* ctx = f->ctx;
+    ++f->opver;
     QCHECK(ctx, hipMemcpyAsync(f->Hraw, H.data(), sizeof(double) * H.size(), hipMemcpyHostToDevice, ctx->stream));
     QCHECK(ctx, hipMemcpyAsync(f->shift, sh.data(), sizeof(double) * m, hipMemcpyHostToDevice, ctx->stream));
     QCHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -966,36 +1019,73 @@ int sq_step(pnmol_sqrt_filter* f, double dt, double* norms_out) {
     const int d = f->ds, n = f->n, m = f->m, D = f->D;   // d: state components here
     const SqConst kc = sq_const(f, dt);
     const QrPlan &q1 = f->q1, &q2 = f->q2;
-    // predict (white.py:101-103, :114): mp = A Pinv m, Cl- = R^T of [(A Pinv Cl)^T; Ql^T]
-    hipLaunchKernelGGL(k_sq_mean, dim3((d + 255) / 256), dim3(256), 0, st, f->mp, f->mean, d, kc);
-    hipLaunchKernelGGL(k_sq_rows, dim3((D + 255) / 256, d), dim3(256), 0, st, f->T1, f->Cl, d, D, kc);
-    QCHECK(ctx, hipMemsetAsync(q1.W, 0, sizeof(double) * (size_t)q1.Mp * q1.ld, st));
-    hipLaunchKernelGGL(k_copy_t, tiles(D, D), dim3(256), 0, st, q1.W, (long)q1.ld, f->T1, (long)D, D, D);
-    const int Dtop = (D + QB - 1) / QB * QB;   // the lower block starts on a row-block boundary
-    QCHECK(ctx, hipMemcpy2DAsync(q1.W + (long)Dtop * q1.ld, sizeof(double) * q1.ld, f->QlT, sizeof(double) * D,
-                                 sizeof(double) * D, D, hipMemcpyDeviceToDevice, st));
-    // (A Pinv Cl)^T is upper triangular up to the n x n point blocks when Cl is lower triangular, Ql^T exactly
-    if (int rc = qr_inplace(ctx, q1, f->cl_tri ? Dtop / QB : 0)) return rc;
-    // update (white.py:104, :120-123): QR of [[R H^T, R], [E^T, 0]]
-    QCHECK(ctx, hipMemsetAsync(q2.W, 0, sizeof(double) * (size_t)q2.Mp * q2.ld, st));
-    hipLaunchKernelGGL(k_rht, tiles(m, D), dim3(256), 0, st, q2.W, (long)q2.ld, q1.W, (long)q1.ld, f->Hraw, D, m, kc);
-    hipLaunchKernelGGL(k_sq_fill_r, dim3((D + 31) / 32, (D + 7) / 8), dim3(32, 8), 0, st, q2.W, (long)q2.ld, m, q1.W,
-                       (long)q1.ld, D);
-    QCHECK(ctx, hipMemcpy2DAsync(q2.W + (long)D * q2.ld, sizeof(double) * q2.ld, f->EtT, sizeof(double) * m,
-                                 sizeof(double) * m, m, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(k_sq_gemv_z, dim3((m + 3) / 4), dim3(256), 0, st, f->z, f->Hraw, f->mp, f->shift, m, D, kc);
+    const int Dtop = (D + QB - 1) / QB * QB;   // lower blocks start on a row-block boundary
     const int mpad = (m + 31) / 32 * 32;
     const size_t trsv_lds = sizeof(double) * (2 * (size_t)mpad + 32 * 33 + 32 + 128);
     if (trsv_lds > 64 * 1024)   // beyond the default dynamic-LDS limit (m > ~3500: 2-D meshes); create() bounds it by 160 KB
         QCHECK(ctx, hipFuncSetAttribute((const void*)k_sq_trsv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)trsv_lds));
+    // mp = A Pinv m, T1 = A Pinv Cl, z = H mp + shift (white.py:101-104)
+    hipLaunchKernelGGL(k_sq_mean, dim3((d + 255) / 256), dim3(256), 0, st, f->mp, f->mean, d, kc);
+    hipLaunchKernelGGL(k_sq_rows, dim3((D + 255) / 256, d), dim3(256), 0, st, f->T1, f->Cl, d, D, kc);
+    hipLaunchKernelGGL(k_sq_gemv_z, dim3((m + 3) / 4), dim3(256), 0, st, f->z, f->Hraw, f->mp, f->shift, m, D, kc);
     if (f->err_dt == dt)   // estimate_error: sigma^2 = z^T Sq^-1 z / m = |Rq^-T z|^2 / m (white.py:159)
         hipLaunchKernelGGL(k_sq_trsv, dim3(1), dim3(1024), trsv_lds, st, f->q3.W, (long)f->q3.ld, m, f->z, f->yq, f->xq,
                            f->normsq);
-    if (int rc = qr_inplace(ctx, q2)) return rc;
-    hipLaunchKernelGGL(k_sq_trsv, dim3(1), dim3(1024), trsv_lds, st, q2.W, (long)q2.ld, m, f->z, f->y, f->x, norms_out);
-    hipLaunchKernelGGL(k_sq_mean_update, dim3((D + 63) / 64), dim3(256), 0, st, f->mean, f->mp, q2.W, (long)q2.ld, m,
+
+    // The reference's two QRs (white.py:114, :120) are one: with [(A Pinv Cl)^T; Ql^T] = Q Rp, the update's pre-array
+    // [[Rp H^T, Rp], [E^T, 0]] and  B = [[T1^T H^T, T1^T], [Ql^T H^T, Ql^T], [E^T, 0]]  differ by an orthogonal factor
+    // from the left, so they have the same R.  The last two block rows of B do not depend on the state: for a linear PDE
+    // under a constant step they are factored ONCE (Rc, upper triangular), and a step is the QR of [[T1^T H^T, T1^T], [Rc]]
+    // -- D dense rows on a triangle, 49 members per panel at N=512 instead of up to 113, two tree levels throughout.
+    // Taken from the second consecutive step with the same (dt, operator) on; before that (and for a semilinear PDE,
+    // whose operator changes every step) the two QRs run as written.
+    const bool repeat = (f->prev_dt == dt && f->prev_op == f->opver);
+    f->prev_dt = dt, f->prev_op = f->opver;
+    const bool disabled = std::getenv("PNMOL_SQRT_ONE_QR") && std::atoi(std::getenv("PNMOL_SQRT_ONE_QR")) == 0;
+    if (repeat && !disabled && !(f->rc_dt == dt && f->rc_op == f->opver)) {
+        QCHECK(ctx, hipMemsetAsync(q2.W, 0, sizeof(double) * (size_t)q2.Mp * q2.ld, st));
+        hipLaunchKernelGGL(k_rht, tiles(m, D), dim3(256), 0, st, q2.W, (long)q2.ld, f->QlT, (long)D, f->Hraw, D, m, kc);
+        QCHECK(ctx, hipMemcpy2DAsync(q2.W + m, sizeof(double) * q2.ld, f->QlT, sizeof(double) * D, sizeof(double) * D, D,
+                                     hipMemcpyDeviceToDevice, st));
+        QCHECK(ctx, hipMemcpy2DAsync(q2.W + (long)D * q2.ld, sizeof(double) * q2.ld, f->EtT, sizeof(double) * m,
+                                     sizeof(double) * m, m, hipMemcpyDeviceToDevice, st));
+        if (int rc = qr_inplace(ctx, q2)) return rc;
+        hipLaunchKernelGGL(k_sq_copy_upper, dim3((q2.ld + 31) / 32, (q2.ld + 7) / 8), dim3(32, 8), 0, st, f->Rc,
+                           (long)q2.ld, q2.W, (long)q2.ld, q2.ld);
+        f->rc_dt = dt, f->rc_op = f->opver;
+    }
+    const QrPlan* qr = &q2;   // where R = [[R1, R2], [0, R3]] ends up
+    if (f->rc_dt == dt && f->rc_op == f->opver && !disabled) {
+        const QrPlan& q4 = f->q4;
+        QCHECK(ctx, hipMemsetAsync(q4.W, 0, sizeof(double) * (size_t)q4.Mp * q4.ld, st));
+        hipLaunchKernelGGL(k_sq_tht, tiles(m, D), dim3(256), 0, st, q4.W, (long)q4.ld, f->T1, f->Hraw, D, m, kc,
+                           f->cl_tri ? 1 : 0);
+        hipLaunchKernelGGL(k_copy_t, tiles(D, D), dim3(256), 0, st, q4.W + m, (long)q4.ld, f->T1, (long)D, D, D);
+        QCHECK(ctx, hipMemcpy2DAsync(q4.W + (long)Dtop * q4.ld, sizeof(double) * q4.ld, f->Rc, sizeof(double) * q2.ld,
+                                     sizeof(double) * q2.ld, q2.ld, hipMemcpyDeviceToDevice, st));
+        if (int rc = qr_inplace(ctx, q4, 0, Dtop / QB)) return rc;
+        qr = &q4;
+    } else {
+        // predict (white.py:114): Cl- = R^T of [(A Pinv Cl)^T; Ql^T]
+        QCHECK(ctx, hipMemsetAsync(q1.W, 0, sizeof(double) * (size_t)q1.Mp * q1.ld, st));
+        hipLaunchKernelGGL(k_copy_t, tiles(D, D), dim3(256), 0, st, q1.W, (long)q1.ld, f->T1, (long)D, D, D);
+        QCHECK(ctx, hipMemcpy2DAsync(q1.W + (long)Dtop * q1.ld, sizeof(double) * q1.ld, f->QlT, sizeof(double) * D,
+                                     sizeof(double) * D, D, hipMemcpyDeviceToDevice, st));
+        // (A Pinv Cl)^T is upper triangular up to the n x n point blocks when Cl is lower triangular, Ql^T exactly
+        if (int rc = qr_inplace(ctx, q1, f->cl_tri ? Dtop / QB : 0)) return rc;
+        // update (white.py:120-123): QR of [[R H^T, R], [E^T, 0]]
+        QCHECK(ctx, hipMemsetAsync(q2.W, 0, sizeof(double) * (size_t)q2.Mp * q2.ld, st));
+        hipLaunchKernelGGL(k_rht, tiles(m, D), dim3(256), 0, st, q2.W, (long)q2.ld, q1.W, (long)q1.ld, f->Hraw, D, m, kc);
+        hipLaunchKernelGGL(k_sq_fill_r, dim3((D + 31) / 32, (D + 7) / 8), dim3(32, 8), 0, st, q2.W, (long)q2.ld, m, q1.W,
+                           (long)q1.ld, D);
+        QCHECK(ctx, hipMemcpy2DAsync(q2.W + (long)D * q2.ld, sizeof(double) * q2.ld, f->EtT, sizeof(double) * m,
+                                     sizeof(double) * m, m, hipMemcpyDeviceToDevice, st));
+        if (int rc = qr_inplace(ctx, q2)) return rc;
+    }
+    hipLaunchKernelGGL(k_sq_trsv, dim3(1), dim3(1024), trsv_lds, st, qr->W, (long)qr->ld, m, f->z, f->y, f->x, norms_out);
+    hipLaunchKernelGGL(k_sq_mean_update, dim3((D + 63) / 64), dim3(256), 0, st, f->mean, f->mp, qr->W, (long)qr->ld, m,
                        f->y, m, D, kc);
-    hipLaunchKernelGGL(k_sq_state_out, tiles(D, D), dim3(256), 0, st, f->Cl, D, q2.W, (long)q2.ld, m, kc);
+    hipLaunchKernelGGL(k_sq_state_out, tiles(D, D), dim3(256), 0, st, f->Cl, D, qr->W, (long)qr->ld, m, kc);
     QCHECK(ctx, hipGetLastError());
     f->t += dt;
     f->cl_tri = true;   // P R3^T
@@ -1018,11 +1108,12 @@ int pnmol_sqrt_filter_destroy(pnmol_sqrt_filter* f) {
     if (!f) return -1;
     hipSetDevice(f->ctx->device);
     for (double* p : {f->Hraw, f->shift, f->EtT, f->QlT, f->mean, f->Cl, f->T1, f->mp, f->z, f->y, f->x, f->norms,
-                      f->sqdiag, f->yq, f->xq, f->normsq})
+                      f->sqdiag, f->yq, f->xq, f->normsq, f->Rc})
         if (p) hipFree(p);
     qr_plan_free(&f->q1);
     qr_plan_free(&f->q2);
     qr_plan_free(&f->q3);
+    qr_plan_free(&f->q4);
     delete f;
     return 0;
 }
@@ -1079,6 +1170,8 @@ int pnmol_sqrt_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmo
         if ((rc = qr_plan_alloc(ctx, (D + QB - 1) / QB * QB + D, D, &f->q1))) { rc = -4; break; }
         if ((rc = qr_plan_alloc(ctx, D + m, m + D, &f->q2))) { rc = -4; break; }
         if ((rc = qr_plan_alloc(ctx, D + m, m, &f->q3))) { rc = -4; break; }
+        if ((rc = qr_plan_alloc(ctx, (D + QB - 1) / QB * QB + f->q2.ld, m + D, &f->q4))) { rc = -4; break; }
+        if (!alloc(&f->Rc, (size_t)f->q2.ld * f->q2.ld)) { rc = -4; break; }
         // Ql^T = (Gamma (x) Lq)^T (base/iwp.py:32-53), E^T = blockdiag(E_sqrtm, R_sqrtm)^T (white.py:184)
         std::vector<double> QlT((size_t)D * D, 0.0), EtT((size_t)m * m, 0.0);
         for (int j = 0; j < ds; ++j)
