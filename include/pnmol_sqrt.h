@@ -41,7 +41,9 @@ int pnmol_sqrt_update_no_meascov(pnmol_ctx* ctx, const double* H, int m, int D, 
 /* ---- the filter step in square-root form ----------------------------------------------------------------------------
  * `_WhiteNoiseEK1Base.attempt_step` as the reference writes it (white.py:96-146): the state is (mean, cov_sqrtm); the
  * predict is `propagate_cholesky_factor(A @ Cl, Ql)` (:114), the update `update_sqrt(H, Clp, E)` (:120), each one QR on
- * the device.  About 40x the flops of the covariance form behind pnmol_hip.h (which is the fast path); this is the
+ * the device -- and, from the second consecutive step with the same (dt, operator) on, ONE QR: the rows of the stacked
+ * pre-array that do not depend on the state are factored once (same R; PNMOL_SQRT_ONE_QR=0 keeps the
+ * two).  About 14x the flops of the covariance form behind pnmol_hip.h (which is the fast path); this is the
  * form to use when the factor itself is wanted, or when the covariance form's resolution (eps |P-|) is not enough.
  * Dense H.  The filter owns ONE state, advanced in place.  `pnmol_filter_desc` as in pnmol_hip.h: d_state 0 or d = white-noise model; d_state = 2d = latent-force model
  * (latent.py:155-233: L = [L, I], B = [B, 0], Gamma = blockdiag(chol K, E_sqrtm), zero noise factors -> the update is

@@ -227,3 +227,19 @@ def test_device_initialisation_matches_oracle_and_host(N, nu, bcond):
     osol = osolver.solve(opde)
     om, os_ = o.read_mean_and_std(osol, osolver.E0)
     assert_mean_std_parity(sol.mean[:, 0], sol.marginal_std[:, 0], om, os_)
+
+
+def test_one_qr_step_equals_the_two_qr_step(monkeypatch):
+    """The step-invariant rows factored once + one structured QR per step (default from the second step on) against the
+    reference's two QRs per step (PNMOL_SQRT_ONE_QR=0): the same R, so the same solve."""
+    N, nu, dt, K = 70, 2, 2.0 ** -7, 6
+    pde, _, _, _ = make_pair(N, nu, dt, K, bcond="neumann")
+    monkeypatch.setenv("PNMOL_SQRT_ONE_QR", "0")
+    t2, m2, s2, sig2, f2 = _sqrt_solver(nu, dt).solve_marginals(pde)
+    monkeypatch.delenv("PNMOL_SQRT_ONE_QR")
+    t1, m1, s1, sig1, f1 = _sqrt_solver(nu, dt).solve_marginals(pde)
+    np.testing.assert_allclose(m1, m2, rtol=1e-9, atol=1e-12 * np.abs(m2).max())
+    np.testing.assert_allclose(s1, s2, rtol=1e-7, atol=1e-12 * s2.max())
+    np.testing.assert_allclose(sig1, sig2, rtol=1e-8)
+    C1, C2 = f1.y.cov_sqrtm, f2.y.cov_sqrtm
+    np.testing.assert_allclose(C1, C2, rtol=1e-6, atol=1e-9 * np.abs(C2).max())
