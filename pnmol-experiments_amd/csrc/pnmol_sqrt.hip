@@ -1016,7 +1016,7 @@ int sq_upload_operator(pnmol_sqrt_filter* f, const double* M, const double* shif
 int sq_step(pnmol_sqrt_filter* f, double dt, double* norms_out) {
     pnmol_ctx* ctx = f->ctx;
     hipStream_t st = ctx->stream;
-    const int d = f->ds, n = f->n, m = f->m, D = f->D;   // d: state components here
+    const int d = f->ds, m = f->m, D = f->D;   // d: state components here
     const SqConst kc = sq_const(f, dt);
     const QrPlan &q1 = f->q1, &q2 = f->q2;
     const int Dtop = (D + QB - 1) / QB * QB;   // lower blocks start on a row-block boundary
