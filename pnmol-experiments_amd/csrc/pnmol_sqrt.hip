@@ -1312,21 +1312,17 @@ int pnmol_sqrt_filter_steps(pnmol_sqrt_filter* f, int k, double dt, double* mean
     const int w = f->ds;   // read-out width: every state component (u, and eps behind it in the latent-force model)
     DevBuf dm, dsd, dn;
     if (dm.alloc((size_t)k * w) || dsd.alloc((size_t)k * w) || dn.alloc((size_t)2 * k)) return -4;
-    hipEvent_t e0, e1;
-    QCHECK(ctx, hipEventCreate(&e0));
-    QCHECK(ctx, hipEventCreate(&e1));
-    QCHECK(ctx, hipEventRecord(e0, ctx->stream));
     int rc = 0;
-    for (int s = 0; s < k && !rc; ++s) {
-        rc = sq_step(f, dt, dn.p + 2 * s);
-        hipLaunchKernelGGL(k_sq_readout, dim3((w + 3) / 4), dim3(256), 0, ctx->stream, dm.p + (size_t)s * w,
-                           dsd.p + (size_t)s * w, f->mean, f->Cl, w, f->n, f->D);
+    {
+        QrTimer tm(ctx->stream);   // HIP events around the loop; its destructor waits for the stop event
+        for (int s = 0; s < k && !rc; ++s) {
+            rc = sq_step(f, dt, dn.p + 2 * s);
+            hipLaunchKernelGGL(k_sq_readout, dim3((w + 3) / 4), dim3(256), 0, ctx->stream, dm.p + (size_t)s * w,
+                               dsd.p + (size_t)s * w, f->mean, f->Cl, w, f->n, f->D);
+        }
+        tm.stop();
     }
-    hipEventRecord(e1, ctx->stream);
-    hipEventSynchronize(e1);
-    hipEventElapsedTime(&f->last_ms, e0, e1);
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    f->last_ms = g_last_qr_ms;
     if (rc) return rc;
     std::vector<double> nrm((size_t)2 * k);
     QCHECK(ctx, hipMemcpyAsync(nrm.data(), dn.p, sizeof(double) * nrm.size(), hipMemcpyDeviceToHost, ctx->stream));
