@@ -243,3 +243,26 @@ def test_one_qr_step_equals_the_two_qr_step(monkeypatch):
     np.testing.assert_allclose(sig1, sig2, rtol=1e-8)
     C1, C2 = f1.y.cov_sqrtm, f2.y.cov_sqrtm
     np.testing.assert_allclose(C1, C2, rtol=1e-6, atol=1e-9 * np.abs(C2).max())
+
+
+def test_two_dimensional_mesh_square_root_form():
+    """2-d Dirichlet heat problem (5-point stencils, nu=1; the shape of BASELINE config 5): 12x12 against the oracle,
+    28x28 (D=1568, m=892: three tree levels, a boundary block of 108 rows) against the covariance form on the GPU."""
+    dt, K = 2.0 ** -8, 6
+    k = pnmol.kernels.Matern52() + pnmol.kernels.WhiteNoise()
+    pde = pnmol.pde.examples.heat_2d_dirichlet_discretized(nums=(12, 12), tmax=K * dt, kernel=pnmol.kernels.SquareExponential())
+    opde = o.heat_2d_dirichlet_discretized(nums=(12, 12), tmax=K * dt, kernel=o.SquareExponential())
+    osolver = o.WhiteNoiseEK1(num_derivatives=1, steprule=o.Constant(dt), canonical_factor_signs=True,
+                              spatial_kernel=o.Matern52() + o.WhiteNoise())
+    t, means, stds, sig, _ = _sqrt_solver(1, dt, kernel=k).solve_marginals(pde)
+    osol = osolver.solve(opde)
+    om, os_ = o.read_mean_and_std(osol, osolver.E0)
+    assert_mean_std_parity(means, stds, om, os_)
+    np.testing.assert_allclose(np.mean(sig), osol.diffusion_squared_calibrated, rtol=1e-5)
+
+    pde = pnmol.pde.examples.heat_2d_dirichlet_discretized(nums=(28, 28), tmax=K * dt, kernel=pnmol.kernels.SquareExponential())
+    tq, mq, sq, sigq, _ = _sqrt_solver(1, dt, kernel=k).solve_marginals(pde)
+    cov = pnmol.white.LinearWhiteNoiseEK1(num_derivatives=1, steprule=pnmol.odetools.step.Constant(dt), spatial_kernel=k)
+    tc, mc, sc, sigc, _ = cov.solve_marginals(pde)
+    assert_mean_std_parity(mc, sc, mq, sq)
+    np.testing.assert_allclose(sigc, sigq, rtol=1e-5)
