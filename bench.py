@@ -103,12 +103,16 @@ def cpu_quota():
 
 def limit_blas_threads():
     """BLAS threads = the CPUs we are actually allowed (more only burns the cgroup quota and gets throttled).
-    Call after the BLAS users (numpy, scipy.linalg: separate OpenBLAS copies) are imported."""
+    Call after the BLAS users (numpy, scipy.linalg: separate OpenBLAS copies) are imported.  Only ever LOWERS a pool:
+    an OpenBLAS that started with OMP_NUM_THREADS=1 (what `torch.distributed.run` exports to its workers) has buffers
+    for one thread, and raising its thread count afterwards segfaults inside the next LAPACK call."""
     try:
         import scipy.linalg  # noqa: F401
-        from threadpoolctl import threadpool_limits
+        from threadpoolctl import threadpool_info, threadpool_limits
         local_ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))   # ranks of this node share the quota
-        threadpool_limits(limits=max(1, cpu_quota() // local_ranks))
+        want = max(1, cpu_quota() // local_ranks)
+        current = [int(p.get("num_threads", want)) for p in threadpool_info()]
+        threadpool_limits(limits=max(1, min([want] + current)))
     except Exception:
         pass
 
