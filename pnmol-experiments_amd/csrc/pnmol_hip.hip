@@ -427,6 +427,254 @@ __device__ __forceinline__ void diag2w_from_lds(const double* T, double* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Four-wave, 4-column-blocked variant of the 32x32 Cholesky + inverse (the one k_sweep uses).
+//
+// The column-at-a-time scheme above spends ~60 instructions per pivot, 43 of them fixed overhead (publication,
+// broadcasts, pivot chain): 5.3 us per block, and 17 blocks in a row are the critical path of the whole filter step.
+// Here a step eliminates FOUR columns:
+//   * the tile lives in MFMA accumulators, NEGATED (n = -T) and symmetric, one 16x16 quadrant per wave as it falls
+//     out of the sweep's own accumulation (no LDS staging).  Read "transposed", accumulator register c of a
+//     quadrant IS the 4-column panel c in MFMA operand layout: lane (row, k) holds T[row][4c + k];
+//   * the 4x4 pivot block is pulled into scalar registers (v_readlane) and factorised + inverted in closed form on
+//     wave-uniform values: only 4 x (rsq -> refine) + two ops between them are sequential;
+//   * -Linv4 is scattered into operand layout by ten FMAs with lane-constant indicators, and ONE MFMA gives the
+//     panel solve  X = B Linv4^T  (as X^T = Linv4 B^T: the result lands in operand layout again), ONE more the
+//     rank-4 trailing update  n += X X^T  of the quadrant that holds the next pivot block.
+// Roles (w = wave): w0 factorises quadrant (0,0) [steps 0..3]; w3 follows it with the panel solve of rows 16..31 and the
+// update of quadrants (0,1), (1,1), then factorises (1,1) [steps 4..7] -- the critical path changes waves once, no
+// register hand-over; w1 gives its quadrant (0,1) to w3 and then builds L^-1 one step behind (same elementary block
+// operations applied to the identity); w2 is free (publishes the row's last tile in k_sweep) and finally writes L.
+// Waves talk through LDS buffers that are written once per block (no reuse hazard) + flags; w0 never waits.
+// Semi-definite pivots: as above (rs = 0 -> zero column of L, zero row/column of L^-1).
+// ------------------------------------------------------------------------------------------
+struct Diag4Lds {
+    double x0[4][64];   // step c < 4: X panel rows 0..15, masked to row >= column, operand layout (lane = row + 16 k)
+    double x1[8][64];   // X panel rows 16..31 (steps 4..7: masked)
+    double la[8][64];   // -Linv4 of step c as MFMA A operand: lane i + 16 k (i < 4, k <= i), 0 elsewhere
+    double n01[4][64];  // quadrant (0,1) of n, handed from w1 to w3
+    double piv[NB];     // the 32 pivots (for the info word)
+    int flagA[8];       // la[c] and x0[c] (c < 4) / x1[c] (c >= 4) are published
+    int flagB[4];       // x1[c], c < 4, is published
+    int flagN;          // n01 is published
+    int pad[3];
+};
+
+__device__ __forceinline__ double rsq_refined(double p) {
+    const double y0 = __builtin_amdgcn_rsq(p);
+    const double e = fma(-(p * y0), y0, 1.0);
+    return fma(y0 * e, fma(0.375, e, 0.5), y0);
+}
+__device__ __forceinline__ void lds_flag_set(int* f) {
+    // LDS operations of one wave execute in issue order: the flag only has to be EMITTED behind the data stores, and
+    // right there -- without the second barrier the compiler sinks the (relaxed) store to the end of the next step
+    asm volatile("" ::: "memory");
+    __hip_atomic_store(f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);  // ... and the scheduler would sink the whole publication behind later ALU work
+}
+__device__ __forceinline__ void lds_flag_wait(const int* f) {
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+
+// lane-constant indicators of the ten entries (i >= k) of the 4x4 operand: ind[e] = (lane == i + 16 k)
+__device__ __forceinline__ void diag4_indicators(double (&ind)[10], int lane) {
+    int e = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k <= i; ++k) ind[e++] = (lane == i + 16 * k) ? 1.0 : 0.0;
+}
+
+// One 4-column step on the 16x16 quadrant accumulator n (negated, symmetric): local columns 4 CP .. 4 CP + 3.
+// thrv: lane l holds the zero-pivot threshold of local row l & 15.  Publishes -Linv4 (la_dst), the masked panel
+// (x_dst) and the pivots, then sets *flag.
+template <int CP>
+__device__ __forceinline__ void diag4_step(d4& n, double thrv, const double (&ind)[10], int lane, double* la_dst,
+                                           double* x_dst, double* piv_dst, int* flag) {
+    const int fr = lane & 15, fk = lane >> 4;
+    const double src = n[CP];  // lane (i', k): -T[i'][4 CP + k]  (row view of the symmetric quadrant)
+#define D4E(i, k) (-bcast_lane(src, 4 * CP + (i) + 16 * (k)))
+    const double p0 = D4E(0, 0);
+    const double r0 = p0 > bcast_lane(thrv, 4 * CP + 0) ? rsq_refined(p0) : 0.0;
+    const double l10 = D4E(1, 0) * r0, l20 = D4E(2, 0) * r0, l30 = D4E(3, 0) * r0;
+    const double p1 = fma(-l10, l10, D4E(1, 1));
+    const double r1 = p1 > bcast_lane(thrv, 4 * CP + 1) ? rsq_refined(p1) : 0.0;
+    const double l21 = fma(-l20, l10, D4E(2, 1)) * r1, l31 = fma(-l30, l10, D4E(3, 1)) * r1;
+    const double p2 = fma(-l21, l21, fma(-l20, l20, D4E(2, 2)));
+    const double r2 = p2 > bcast_lane(thrv, 4 * CP + 2) ? rsq_refined(p2) : 0.0;
+    const double l32 = fma(-l31, l21, fma(-l30, l20, D4E(3, 2))) * r2;
+    const double p3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, D4E(3, 3))));
+    const double r3 = p3 > bcast_lane(thrv, 4 * CP + 3) ? rsq_refined(p3) : 0.0;
+#undef D4E
+    // Linv4 (lower): rows scaled by r_i; everything that does not need r3 is ready before it
+    const double i10 = -(l10 * r0) * r1;
+    const double i21 = -(l21 * r1) * r2;
+    const double i20 = -fma(l21, i10, l20 * r0) * r2;
+    const double s32 = l32 * r2, s31 = fma(l32, i21, l31 * r1), s30 = fma(l32, i20, fma(l31, i10, l30 * r0));
+    // la = -Linv4 in operand layout (rows i < 4 of the A operand -> the product lands in accumulator register 0)
+    double la = ind[0] * -r0;
+    la = fma(ind[1], -i10, la);
+    la = fma(ind[2], -r1, la);
+    la = fma(ind[3], -i20, la);
+    la = fma(ind[4], -i21, la);
+    la = fma(ind[5], -r2, la);
+    double lb = ind[6] * (s30 * r3);
+    lb = fma(ind[7], s31 * r3, lb);
+    lb = fma(ind[8], s32 * r3, lb);
+    lb = fma(ind[9], -r3, lb);
+    la += lb;
+    const d4 zero = {0, 0, 0, 0};
+    const d4 xo = __builtin_amdgcn_mfma_f64_16x16x4f64(la, src, zero, 0, 0, 0);  // [0]: lane (row, i) = X[row][i]
+    const double x = (fr >= 4 * CP + fk) ? xo[0] : 0.0;                            // finished rows / upper part of L4: 0
+    if constexpr (CP < 3) n = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, n, 0, 0, 0);
+    la_dst[lane] = la;
+    x_dst[lane] = x;
+    piv_dst[0] = p0;  // wave-uniform values: every lane stores the same words (no divergent branch in the stream)
+    piv_dst[1] = p1;
+    piv_dst[2] = p2;
+    piv_dst[3] = p3;
+    lds_flag_set(flag);
+}
+
+// w3, step C < 4: panel solve of rows 16..31 and the update of quadrants (0,1) and (1,1)
+template <int C>
+__device__ __forceinline__ void diag4_panel_step(d4& n01, d4& n11, Diag4Lds* L, int lane) {
+    lds_flag_wait(&L->flagA[C]);
+    const double la = L->la[C][lane], x0 = L->x0[C][lane];
+    const d4 zero = {0, 0, 0, 0};
+    const d4 xo = __builtin_amdgcn_mfma_f64_16x16x4f64(la, n01[C], zero, 0, 0, 0);
+    const double x1 = xo[0];
+    n11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, n11, 0, 0, 0);
+    if constexpr (C < 3) n01 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x1, n01, 0, 0, 0);
+    L->x1[C][lane] = x1;
+    lds_flag_set(&L->flagB[C]);
+}
+
+// w1, step C: the block operations of step C applied to W (starts as the identity, ends as L^-1; natural layout,
+// quadrants (0,0), (1,0), (1,1))
+template <int C>
+__device__ __forceinline__ void diag4_inverse_step(d4& w00, d4& w10, d4& w11, Diag4Lds* L, int lane) {
+    const d4 zero = {0, 0, 0, 0};
+    lds_flag_wait(&L->flagA[C]);
+    const double la = L->la[C][lane];
+    if constexpr (C < 4) {
+        const double x0 = L->x0[C][lane];
+        const double yn = __builtin_amdgcn_mfma_f64_16x16x4f64(la, w00[C], zero, 0, 0, 0)[0];  // -Linv4 W[block rows]
+        w00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, yn, w00, 0, 0, 0);
+        lds_flag_wait(&L->flagB[C]);
+        const double x1 = L->x1[C][lane];
+        w10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, yn, w10, 0, 0, 0);
+        w00[C] = -yn;
+    } else {
+        constexpr int CP = C - 4;
+        const double yn0 = __builtin_amdgcn_mfma_f64_16x16x4f64(la, w10[CP], zero, 0, 0, 0)[0];
+        const double yn1 = __builtin_amdgcn_mfma_f64_16x16x4f64(la, w11[CP], zero, 0, 0, 0)[0];
+        if constexpr (C < 7) {
+            const double x1 = L->x1[C][lane];
+            w10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, yn0, w10, 0, 0, 0);
+            w11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, yn1, w11, 0, 0, 0);
+        }
+        w10[CP] = -yn0;
+        w11[CP] = -yn1;
+    }
+}
+
+// Called by all four waves of a workgroup.  nq = this wave's quadrant (w >> 1, w & 1) of n = -T in accumulator layout
+// (quadrant (1,0) of w2 is not used; quadrant (0,1) holds the transposed LOWER entries).  L->flag*: zero on entry.
+// Fd (leading dim ld): L, upper part zeroed.  Li: L^-1 (32x32; its upper-right quadrant is never written: the caller
+// keeps it zero).  Returns after this wave's part; w1 returns with its L^-1 stores issued, not drained.
+template <bool WT>
+__device__ __forceinline__ void diag4_factor(const d4& nq, Diag4Lds* L, int w, int lane, double* __restrict__ Fd, long ld,
+                                             double* __restrict__ Li, int* info, int base, const double* sd_blk, double smax) {
+    const int fr = lane & 15, fk = lane >> 4;
+    if (w == 0) {
+        d4 n = nq;
+        double ind[10];
+        diag4_indicators(ind, lane);
+        const double thrv = 1e-13 * fabs(sd_blk[fr]);
+        diag4_step<0>(n, thrv, ind, lane, L->la[0], L->x0[0], L->piv + 0, &L->flagA[0]);
+        diag4_step<1>(n, thrv, ind, lane, L->la[1], L->x0[1], L->piv + 4, &L->flagA[1]);
+        diag4_step<2>(n, thrv, ind, lane, L->la[2], L->x0[2], L->piv + 8, &L->flagA[2]);
+        diag4_step<3>(n, thrv, ind, lane, L->la[3], L->x0[3], L->piv + 12, &L->flagA[3]);
+    } else if (w == 3) {
+        d4 n11 = nq, n01;
+        double ind[10];
+        diag4_indicators(ind, lane);
+        const double thrv = 1e-13 * fabs(sd_blk[16 + fr]);
+        lds_flag_wait(&L->flagN);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) n01[r] = L->n01[r][lane];
+        diag4_panel_step<0>(n01, n11, L, lane);
+        diag4_panel_step<1>(n01, n11, L, lane);
+        diag4_panel_step<2>(n01, n11, L, lane);
+        diag4_panel_step<3>(n01, n11, L, lane);
+        diag4_step<0>(n11, thrv, ind, lane, L->la[4], L->x1[4], L->piv + 16, &L->flagA[4]);
+        diag4_step<1>(n11, thrv, ind, lane, L->la[5], L->x1[5], L->piv + 20, &L->flagA[5]);
+        diag4_step<2>(n11, thrv, ind, lane, L->la[6], L->x1[6], L->piv + 24, &L->flagA[6]);
+        diag4_step<3>(n11, thrv, ind, lane, L->la[7], L->x1[7], L->piv + 28, &L->flagA[7]);
+    } else if (w == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) L->n01[r][lane] = nq[r];
+        lds_flag_set(&L->flagN);
+        d4 w00, w10 = {0, 0, 0, 0}, w11;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w00[r] = (fk + 4 * r == fr) ? 1.0 : 0.0;
+        w11 = w00;
+        diag4_inverse_step<0>(w00, w10, w11, L, lane);
+        diag4_inverse_step<1>(w00, w10, w11, L, lane);
+        diag4_inverse_step<2>(w00, w10, w11, L, lane);
+        diag4_inverse_step<3>(w00, w10, w11, L, lane);
+        diag4_inverse_step<4>(w00, w10, w11, L, lane);
+        diag4_inverse_step<5>(w00, w10, w11, L, lane);
+        diag4_inverse_step<6>(w00, w10, w11, L, lane);
+        diag4_inverse_step<7>(w00, w10, w11, L, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double* p00 = &Li[(fk + 4 * r) * NB + fr];
+            double* p10 = &Li[(16 + fk + 4 * r) * NB + fr];
+            if constexpr (WT) {
+                __hip_atomic_store(p00, w00[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p10, w10[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p10 + 16, w11[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                *p00 = w00[r];
+                *p10 = w10[r];
+                p10[16] = w11[r];
+            }
+        }
+    } else {  // w == 2: L itself (nobody inside the sweep reads a diagonal tile) and the info word
+        lds_flag_wait(&L->flagA[7]);
+        lds_flag_wait(&L->flagB[3]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            Fd[(long)fr * ld + 4 * c + fk] = L->x0[c][lane];
+            Fd[(long)(16 + fr) * ld + 4 * c + fk] = L->x1[c][lane];
+            Fd[(long)fr * ld + 16 + 4 * c + fk] = 0.0;
+            Fd[(long)(16 + fr) * ld + 16 + 4 * c + fk] = L->x1[4 + c][lane];
+        }
+        if (lane < NB) {
+            const double pv = L->piv[lane], sdv = fabs(sd_blk[lane]);
+            const bool fatal = !(pv > 1e-13 * sdv) && (!(pv == pv) || (pv < -1e-3 * sdv && sdv > 1e-12 * smax));
+            const unsigned long long mk = __ballot(fatal);
+            if (mk != 0 && lane == 0) atomicMin(info, base + __builtin_ctzll(mk));
+        }
+    }
+}
+
+// this wave's quadrant (w >> 1, w & 1) of -T from a symmetric tile in LDS (leading dimension TLD), lower entries only
+__device__ __forceinline__ d4 diag4_quadrant_from_lds(const double* T, int w, int lane) {
+    const int fr = lane & 15, fk = lane >> 4, qi = w >> 1, qj = w & 1;
+    d4 n;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 16 * qi + fk + 4 * r, col = 16 * qj + fr;
+        n[r] = -(row >= col ? T[row * TLD + col] : T[col * TLD + row]);
+    }
+    return n;
+}
+
 __device__ __forceinline__ void tile_g2s(const double* __restrict__ g, long ld, double* s, int tid) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -641,8 +889,8 @@ struct SweepLds {
     double red[4];
     int seen[3];             // row[j], row[j+1], diag[j] as last polled
     int dead, pub;
+    Diag4Lds d4;             // the diagonal block's four-wave factorisation (flags zeroed at kernel start)
 };
-static_assert(sizeof(Diag2wLds) <= 4 * NB * TLD * sizeof(double), "Diag2wLds must fit in sP");
 
 __device__ __forceinline__ int flag_ld(const int* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1118,6 +1366,7 @@ __global__ __launch_bounds__(256) void k_sweep(const double* __restrict__ G, dou
         if (l == 0) L.red[w] = smax;
         if (tid < NB) L.sd[tid] = G[(long)(I * NB + tid) * ld + I * NB + tid];
     }
+    if (tid < 16) L.d4.flagA[tid] = 0;  // flagA[8], flagB[4], flagN, pad: contiguous
     if (tid == 0) {
         L.dead = 0, L.pub = 0;
         // One invalidate per workgroup: no copy of F / Linv from before this launch survives in this CU's L1 or this
@@ -1137,10 +1386,16 @@ __global__ __launch_bounds__(256) void k_sweep(const double* __restrict__ G, dou
     const int colC = wc * 16 + fr;
     const int offC = (wr * 16 + fk) * TLD + colC;   // the same position in an LDS tile (rows stride 4 * TLD)
     const double* Xown = F + ((long)I * NB + fr) * ld + 8 * fk;  // A fragments of my own row block: X_k = F[I][k]
+    // accD = this wave's quadrant (wr, wc) of -D, D = G_II - sum_k X_k X_k^T (negated: the updates are plain
+    // accumulations, and it is the form diag4_factor takes).  Only the lower entries of G_II are read: quadrant
+    // (0, 1) starts as the transpose of (1, 0) and stays it (its updates are the same products, transposed).
     d4 accD = {0, 0, 0, 0};
     if (chain) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) accD[r] = G[(rowC + 4 * r) * ld + (long)I * NB + colC];
+        for (int r = 0; r < 4; ++r) {
+            const int rl = wr * 16 + fk + 4 * r, cl = colC;
+            accD[r] = -G[((long)I * NB + (rl >= cl ? rl : cl)) * ld + (long)I * NB + (rl >= cl ? cl : rl)];
+        }
     }
 
     const int nsteps = chain ? I : CB;
@@ -1236,7 +1491,7 @@ __global__ __launch_bounds__(256) void k_sweep(const double* __restrict__ G, dou
         for (int r = 0; r < 4; ++r) L.sX[offC + 4 * r * TLD] = x[r];
         sn = SweepSeen{sn.rown, 0, 0};  // flags of step j+1: row[j+1] is already known this far
         __syncthreads();                // sX (and sP) complete
-        if (w == 3) {  // one wave publishes the tile; the stores complete behind the other waves' next instructions
+        if (w == 2) {  // one wave publishes the tile; the stores complete behind the other waves' next instructions
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int idx = l + 64 * e, row = idx >> 5, col = idx & 31;
@@ -1246,10 +1501,10 @@ __global__ __launch_bounds__(256) void k_sweep(const double* __restrict__ G, dou
         if (chain) {
 #pragma unroll
             for (int s = 0; s < 8; ++s)
-                accD = __builtin_amdgcn_mfma_f64_16x16x4f64(-L.sX[(wr * 16 + fr) * TLD + 8 * fk + s],
+                accD = __builtin_amdgcn_mfma_f64_16x16x4f64(L.sX[(wr * 16 + fr) * TLD + 8 * fk + s],
                                                             L.sX[(wc * 16 + fr) * TLD + 8 * fk + s], accD, 0, 0, 0);
         }
-        if ((!chain || j + 1 < nsteps) && w == 3) {  // (a chain row's last tile is published during its factorisation)
+        if ((!chain || j + 1 < nsteps) && w == 2) {  // (a chain row's last tile is published during its factorisation)
             drain_vmem();
             if (l == 0) flag_st(frow + I, j + 1);
         }
@@ -1262,7 +1517,7 @@ __global__ __launch_bounds__(256) void k_sweep(const double* __restrict__ G, dou
             const int RBW = RT - 2 * CB - 1, zb = CB + RBW;
             if (I != zb) {
                 SWEEP_STAMP(1);
-                __syncthreads();  // wave 3 has drained this row block's last tile
+                __syncthreads();  // the publishing wave has drained this row block's last tile
                 if (tid == 0 && !L.dead) {
                     for (int spins = 0; flag_ld(frow + zb) < CB; ++spins) {
                         if (spins > SWEEP_SPIN_LIMIT || flag_ld(fabort)) {
@@ -1286,32 +1541,25 @@ __global__ __launch_bounds__(256) void k_sweep(const double* __restrict__ G, dou
         return;
     }
 
-    // block (I, I): factorise, publish L_II^-1
-    double* sT = L.sS[0];
-    Diag2wLds* dl = reinterpret_cast<Diag2wLds*>(&L.sP[0][0]);
-    __syncthreads();  // the last step's reads of sS / sP are done
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sT[offC + 4 * r * TLD] = accD[r];
-    if (tid < NB) dl->flag[tid] = 0;
-    __syncthreads();
+    // block (I, I): factorise, publish L_II^-1.  No barrier: every wave goes straight into its role of the four-wave
+    // scheme (diag4_factor) with its quadrant of -D in registers.
     SWEEP_STAMP(3);
-    if (w < 2) {
-        diag2w_from_lds<true>(sT, F + ((long)I * NB) * ld + (long)I * NB, ld, Linv + (long)I * NB * NB, w, l, info,
-                              I * NB, L.sd, smax, dl);
-        if (w == 1) {
-            drain_vmem();  // L^-1 has reached memory
-            if (I > 0) {
-                int spins = 0;
-                while (__hip_atomic_load(&L.pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0 && ++spins < (1 << 24))
-                    __builtin_amdgcn_s_sleep(1);
-            }
-            if (l == 0) flag_st(fdiag + I, 1);
-            SWEEP_STAMP_L(4);
-        }
-    } else if (w == 3 && I > 0) {
+    if (w == 2 && I > 0) {
         drain_vmem();  // the last tile of row I has reached memory
         if (l == 0) flag_st(frow + I, I);
         __hip_atomic_store(&L.pub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    diag4_factor<true>(accD, &L.d4, w, l, F + ((long)I * NB) * ld + (long)I * NB, ld, Linv + (long)I * NB * NB, info, I * NB,
+                       L.sd, smax);
+    if (w == 1) {
+        drain_vmem();  // L^-1 has reached memory
+        if (I > 0) {
+            int spins = 0;
+            while (__hip_atomic_load(&L.pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0 && ++spins < (1 << 24))
+                __builtin_amdgcn_s_sleep(1);
+        }
+        if (l == 0) flag_st(fdiag + I, 1);
+        SWEEP_STAMP_L(4);
     }
     if (tid == 0 && L.dead) atomicMin(info, -2);
     if constexpr (CHAINHELP) {
@@ -2147,6 +2395,7 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
     FCHK(hipMalloc(&f->G, sizeof(double) * tall));
     FCHK(hipMalloc(&f->F, sizeof(double) * tall));
     FCHK(hipMalloc(&f->Linv, sizeof(double) * (size_t)f->CB * NB * NB));
+    FCHK(hipMemset(f->Linv, 0, sizeof(double) * (size_t)f->CB * NB * NB));  // (upper-right quadrants stay zero: diag4_factor)
     FCHK(hipMalloc(&f->Ppred, sizeof(double) * (size_t)Dp * Dp));
     FCHK(hipMalloc(&f->tmpP, sizeof(double) * (size_t)Dp * Dp));
     FCHK(hipMalloc(&f->mpred, sizeof(double) * Dp));
@@ -2532,6 +2781,7 @@ int pnmol_state_get_cov_sqrtm(const pnmol_state* s, double* C_DD) {
         frame_scales(s, sc);
         e = hipMemcpy(dsc, sc, sizeof(double) * MAXN, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemsetAsync(Fc, 0, sizeof(double) * (size_t)Dq * Dq, st);
+        if (e == hipSuccess) e = hipMemsetAsync(Lc, 0, sizeof(double) * (size_t)cb * NB * NB, st);
         if (e == hipSuccess) e = hipMemsetAsync(f->flags, 0, sizeof(int) * (2 * cb + 1), st);
         if (e == hipSuccess) e = hipMemsetAsync(f->info_err, 0x7f, sizeof(int), st);
         if (e == hipSuccess) {
