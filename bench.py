@@ -6,16 +6,23 @@ N=512, nu=2 (BASELINE.json metric / configs).  Each rank owns ONE independent pr
 diffusion-coefficient sweep kappa_g = 0.01 * 10^(g/7): weak scaling, no collective
 in the data path; RCCL only gathers the per-rank read-outs at the end.
 
-Prints ONE JSON line (rank 0).  `value` = steps of all ranks / max-over-ranks wall time of the timed
-region (barrier + device sync on both sides).  `roofline` prices the whole step against the fp64
+Prints ONE JSON line (rank 0).  The timed region is K steps in one device call, bracketed by a barrier and a
+device sync on both sides, max over ranks; it is repeated `--repeats` (5) times and `value` / `ms_per_step`
+are the MEDIAN repeat (`ms_per_step_all` lists them).  `roofline` prices the whole step against the fp64
 MFMA peak with the ALGORITHMIC flop count F_alg of SURVEY.md section 8d (never the padded/dense count);
 `cpu_baseline` times the oracle (reference algorithm as written, NumPy/LAPACK) on this box's cores.
+At N=1 the line also carries (each driver-timed inside this run):
+  batch8_on_1gpu   the 8-problem kappa sweep on this ONE GPU, problems one after the other and all in flight
+                   -- the 1-GPU baseline north_star's ">= 6x at 8 GPUs on an 8-problem batch" refers to
+  secondary        ms/step at N=256, N=1024 and on the 64x64 2-d mesh (BASELINE configs 1, 2, 4; fp64)
+  library_baseline_ms_per_step   the same step written with torch-ROCm library calls (tools/torch_library_step.py)
 """
 
 import argparse
 import json
 import os
 import pathlib
+import subprocess
 import sys
 import time
 
@@ -33,10 +40,11 @@ def f_alg(D, m, n):
     return m ** 3 / 3 + m ** 2 * D + D ** 2 * m + 4 * n * D ** 2 + 8 * (D * m + m ** 2)
 
 
-def build_problem(kappa, K):
+def build_problem(kappa, K, mesh_n=None):
     import pnmol
+    N = MESH_N if mesh_n is None else mesh_n
     pde = pnmol.pde.examples.heat_1d_discretized(
-        bbox=[0.0, 1.0], dx=1.0 / (MESH_N - 1), stencil_size_interior=3, stencil_size_boundary=3, t0=0.0,
+        bbox=[0.0, 1.0], dx=1.0 / (N - 1), stencil_size_interior=3, stencil_size_boundary=3, t0=0.0,
         tmax=K * DT, diffusion_rate=kappa, kernel=pnmol.kernels.SquareExponential(), nugget_gram_matrix_fd=0.0,
         bcond="dirichlet")
     solver = pnmol.white.LinearWhiteNoiseEK1(
@@ -125,12 +133,106 @@ def _hip_device_count():
     return n.value
 
 
+def _bound_problem(kappa, K, device, mesh_n=None):
+    """(context, device filter, device state) of one problem of the sweep, initialised and ready to step."""
+    from pnmol import _hip
+    pde, solver = build_problem(kappa, K, mesh_n)
+    ctx = _hip.Context(device)                        # own stream per problem
+    solver._context = ctx
+    state = solver.initialize(pde)
+    solver._ensure_error_model(pde, DT)
+    return ctx, solver._device_filter, state.y.device_state
+
+
+def batch8_on_one_gpu(device, K):
+    """north_star's 8-problem batch (kappa sweep, N=512, nu=2) on ONE GPU: problems one after the other, and all eight in
+    flight (one stream each).  Steps/s of the whole batch; device work only (state resident, graphs prepared)."""
+    from pnmol import batch
+    probs = [_bound_problem(batch.diffusion_sweep(g, 8), 2 * K + 4, device) for g in range(8)]
+    for _, flt, dev in probs:
+        flt.steps(dev, 2, DT)
+        flt.prepare_steps(dev, K, DT)
+    time.sleep(0.2)
+    for ctx, _, _ in probs:
+        ctx.synchronize()
+    t0 = time.perf_counter()
+    for ctx, flt, dev in probs:                       # serial: each problem alone on the device
+        flt.steps_begin(dev, K, DT)
+        flt.steps_end(dev, want_means=True, want_stds=True)
+    serial = time.perf_counter() - t0
+    for _, flt, dev in probs:
+        flt.prepare_steps(dev, K, DT)
+    for ctx, _, _ in probs:
+        ctx.synchronize()
+    t0 = time.perf_counter()
+    for _, flt, dev in probs:                         # concurrent: enqueue all, then collect
+        flt.steps_begin(dev, K, DT)
+    res = [flt.steps_end(dev, want_means=True, want_stds=True) for _, flt, dev in probs]
+    conc = time.perf_counter() - t0
+    ok = all(np.all(np.isfinite(m)) and all(o.info == -1 for o in infos) for m, _, infos in res)
+    return {"problems": 8, "steps_each": K, "serial_steps_per_s": 8 * K / serial, "concurrent_steps_per_s": 8 * K / conc,
+            "valid": bool(ok)}
+
+
+def secondary_points(device):
+    """BASELINE configs 1, 2 and 4 (fp64): ms per step of the device loop, HIP events on the launch stream."""
+    out = []
+    for mesh_n, K in ((256, 40), (1024, 20)):
+        try:
+            ctx, flt, dev = _bound_problem(0.05, K + 4, device, mesh_n)
+            flt.steps(dev, 2, DT)
+            flt.prepare_steps(dev, K, DT)
+            flt.steps(dev, K, DT)
+            ms = flt.last_steps_ms() / K
+            n, d = NU + 1, mesh_n
+            out.append({"workload": f"1-D heat N={mesh_n} nu={NU}", "ms_per_step": ms,
+                        "frac_of_fp64_mfma_peak": f_alg(n * d, d + 2, n) / (ms * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS})
+            del ctx, flt, dev
+        except Exception as e:   # a secondary point must never take the headline line down
+            out.append({"workload": f"1-D heat N={mesh_n} nu={NU}", "error": repr(e)[:200]})
+    try:
+        import pnmol
+        dt2, K = 2.0 ** -9, 4
+        pde = pnmol.pde.examples.heat_2d_dirichlet_discretized(nums=(64, 64), tmax=(K + 2) * dt2, diffusion_rate=0.05,
+                                                               kernel=pnmol.kernels.SquareExponential())
+        solver = pnmol.white.LinearWhiteNoiseEK1(num_derivatives=1, steprule=pnmol.odetools.step.Constant(dt2),
+                                                 spatial_kernel=pnmol.kernels.Matern52() + pnmol.kernels.WhiteNoise())
+        state = solver.initialize(pde)
+        flt, dev = solver._device_filter, state.y.device_state
+        solver._ensure_error_model(pde, dt2)
+        flt.steps(dev, 1, dt2)
+        flt.prepare_steps(dev, K, dt2)
+        flt.steps(dev, K, dt2)
+        ms = flt.last_steps_ms() / K
+        dd = flt.dims()
+        D, mm, nn = dd["n"] * dd["d"], dd["m"], dd["n"]
+        out.append({"workload": "2-D heat 64x64 mesh nu=1 (fp64)", "ms_per_step": ms,
+                    "frac_of_fp64_mfma_peak": f_alg(D, mm, nn) / (ms * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS})
+    except Exception as e:
+        out.append({"workload": "2-D heat 64x64 mesh nu=1 (fp64)", "error": repr(e)[:200]})
+    return out
+
+
+def library_baseline_ms():
+    """tools/torch_library_step.py (rocBLAS / rocSOLVER through torch) in a child process with a time limit: the first
+    `import torch` on a fresh box can take minutes."""
+    try:
+        out = subprocess.run([sys.executable, str(ROOT / "tools" / "torch_library_step.py"), "--steps", "30"],
+                             capture_output=True, text=True, timeout=float(os.environ.get("PNMOL_BENCH_LIB_TIMEOUT", "240")))
+        return json.loads(out.stdout.strip().splitlines()[-1])["ms_per_step"]
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=5, help="timed repeats of the K-step region; the median is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip batch8_on_1gpu, the secondary points and the library baseline (N=1 only has them)")
     ap.add_argument("--problems-per-gpu", type=int, default=1,
                     help="independent problems run concurrently on each GPU (one context/stream and host thread each); "
                          "the headline metric uses 1")
@@ -158,21 +260,17 @@ def main():
     coll_dev = "cuda" if os.environ.get("PNMOL_BENCH_BACKEND", "nccl") == "nccl" else "cpu"
     os.environ["PNMOL_HIP_DEVICE"] = str(local_rank)
 
-    from pnmol import _hip, batch
+    from pnmol import batch
     B = max(1, args.problems_per_gpu)
+    device = local_rank % max(1, _hip_device_count())
     # one problem per rank: problem g of the 8-problem diffusion sweep (kappa = 0.05 for the single-GPU headline);
     # with --problems-per-gpu B every rank owns B consecutive problems of a (world*B)-problem sweep
-    probs = []
+    probs, kappas = [], []
     for b in range(B):
         gidx = rank * B + b
         kappa = 0.05 if world * B == 1 else batch.diffusion_sweep(gidx, max(world * B, 8))
-        pde, solver = build_problem(kappa, args.steps + args.warmup)
-        ctx = _hip.Context(local_rank % max(1, _hip_device_count()))   # own stream per problem
-        solver._context = ctx
-        state = solver.initialize(pde)
-        flt, dev = solver._device_filter, state.y.device_state
-        solver._ensure_error_model(pde, DT)
-        probs.append((ctx, flt, dev))
+        kappas.append(kappa)
+        probs.append(_bound_problem(kappa, args.warmup + args.steps * max(1, args.repeats), device))
 
     def sync_all():
         for ctx, _, _ in probs:
@@ -190,18 +288,27 @@ def main():
 
     if args.warmup > 0:
         run_all(args.warmup, False)
-    for _, flt, dev in probs:
-        flt.prepare_steps(dev, args.steps, DT)   # one-off host work (buffers, hipGraph instantiation)
-    # The host-side setup above (LAPACK on many threads) can exhaust the container's CPU quota; the kernel then
-    # throttles the whole process for the rest of the 100 ms period, which shows up as a 20-90 ms hole in a 10-20 ms
-    # timed region (seen in 1 of 6 runs at N=256).  Let the quota refill before timing; the GPU work is unaffected.
-    time.sleep(float(os.environ.get("PNMOL_BENCH_SETTLE", "0.3")))
-    sync_all()
-    t0 = time.perf_counter()
-    results = run_all(args.steps, True)                       # K steps per problem, one host sync at the end
-    sync_all()
-    wall = time.perf_counter() - t0
-    dev_ms = max(p[1].last_steps_ms() for p in probs)         # HIP events on each problem's stream
+    walls, devs, results = [], [], None
+    for rep in range(max(1, args.repeats)):
+        for _, flt, dev in probs:
+            flt.prepare_steps(dev, args.steps, DT)   # one-off host work (buffers, hipGraph instantiation)
+        # The host-side setup above (LAPACK on many threads) can exhaust the container's CPU quota; the kernel then
+        # throttles the whole process for the rest of the 100 ms period, which shows up as a 20-90 ms hole in a 10-20 ms
+        # timed region (seen in 1 of 6 runs at N=256).  Let the quota refill before timing; the GPU work is unaffected.
+        if rep == 0:
+            time.sleep(float(os.environ.get("PNMOL_BENCH_SETTLE", "0.3")))
+        sync_all()
+        t0 = time.perf_counter()
+        results = run_all(args.steps, True)                   # K steps per problem, one host sync at the end
+        sync_all()
+        wall = time.perf_counter() - t0
+        if dist is not None:
+            wall = batch.max_over_ranks(wall, dist, device=coll_dev)
+        walls.append(wall)
+        devs.append(max(p[1].last_steps_ms() for p in probs))  # HIP events on each problem's stream
+    order = np.argsort(walls)
+    med = int(order[len(order) // 2])
+    wall, dev_ms = walls[med], devs[med]
     means, stds, infos = results[0]
     for mm_, ss_, ii_ in results[1:]:
         means, stds = np.concatenate([means, mm_]), np.concatenate([stds, ss_])
@@ -209,11 +316,13 @@ def main():
 
     sig = np.array([o.diffusion_squared_local for o in infos])
     ok = bool(np.all(np.isfinite(means)) and np.all(np.isfinite(stds)) and all(o.info == -1 for o in infos))
+    kappa_by_rank = [kappas]
     if dist is not None:
-        wall = batch.max_over_ranks(wall, dist, device=coll_dev)
         # the final gather of the per-problem read-outs -- the only collective of the path (RCCL over xGMI)
         gathered = batch.gather_readouts(np.concatenate([means.ravel(), stds.ravel(), sig]), dist, device=coll_dev)
-        ok = bool(batch.max_over_ranks(0.0 if ok else 1.0, dist, device=coll_dev) == 0.0) and gathered.shape[0] == world
+        assert gathered.shape[0] == world, f"gathered read-outs of {gathered.shape[0]} ranks, world is {world}"
+        kappa_by_rank = batch.gather_readouts(np.array(kappas), dist, device=coll_dev).tolist()
+        ok = bool(batch.max_over_ranks(0.0 if ok else 1.0, dist, device=coll_dev) == 0.0) and bool(np.all(np.isfinite(gathered)))
 
     if rank == 0:
         n, d = NU + 1, MESH_N
@@ -224,10 +333,11 @@ def main():
         # per-step device time is the wall time of the whole batch divided by all its steps.
         step_ms_dev = dev_ms / args.steps if B == 1 else 1e3 * wall / (args.steps * B)
         achieved = flops / (step_ms_dev * 1e-3) / 1e12
-        traffic = None
+        traffic, traffic_src = None, None
         try:   # HBM bytes per step from the committed PMC profile (rocprofv3 cannot run inside this process)
             if MESH_N == 512:
-                traffic = json.load(open(ROOT / "profiles" / "traffic.json"))["hbm_bytes_per_step"]
+                tj = json.load(open(ROOT / "profiles" / "traffic.json"))
+                traffic, traffic_src = tj["hbm_bytes_per_step"], tj.get("source")
         except Exception:
             pass
         line = {
@@ -235,18 +345,27 @@ def main():
             "value": steps_per_s, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "repeats": len(walls), "ms_per_step_all": [1e3 * w / args.steps for w in walls],
             "config": {"workload": f"1-D heat equation, N={MESH_N} mesh, IWP(nu={NU}) EK1, Dirichlet, dt=2^-7, "
                                    f"one problem per GPU (kappa sweep), D={D}, m={m}",
                        "steps_in_one_call": args.steps, "valid": ok, "problems_per_gpu": B,
-                       "device_ms_per_step": step_ms_dev},
+                       "device_ms_per_step": step_ms_dev, "kappa_by_rank": kappa_by_rank},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
+                         "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "note": "unit = one filter step (the kernel graph of one predict+update): F_alg = %.4g "
-                                 "flop/step (SURVEY 8d), duration = HIP events on the launch stream / steps; "
-                                 "traffic = HBM bytes/step from profiles/ (PMC), B_alg = %.3g" % (flops, 3 * D * D * 8)},
+                                 "flop/step (SURVEY 8d), duration = HIP events on the launch stream / steps (median "
+                                 "repeat); traffic = HBM bytes/step from the committed PMC profile (not of this run), "
+                                 "B_alg = %.3g" % (flops, 3 * D * D * 8)},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+        if world == 1:
+            line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline()
+            if not args.no_extras and B == 1 and MESH_N == 512:
+                del probs[:]                                  # release the headline problem's device memory first
+                line["batch8_on_1gpu"] = batch8_on_one_gpu(device, args.steps)
+                line["secondary"] = secondary_points(device)
+                line["library_baseline_ms_per_step"] = library_baseline_ms()
+        else:
+            line["cpu_baseline"] = None      # (reported by the N=1 line, with batch8_on_1gpu as the scaling reference)
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

@@ -2437,7 +2437,7 @@ enum StepKind { STEP_FULL = 0, STEP_FIRST = 1, STEP_STEADY = 2 };
 
 inline bool fused_loop(const pnmol_filter* f) { return f->sweep_mode == 2 && f->n <= 3 && f->fuse_predict != 0; }
 
-// the sweep launch: right-looking register-resident kernel where the row block fits (CB <= 33: N <= 1024 in 1-d),
+// the sweep launch: right-looking register-resident kernel where the row block fits the registers (CB <= 17: N <= 512 in 1-d),
 // the left-looking one otherwise (PNMOL_HIP_SWEEP_RL=0 forces it, for A/B runs)
 inline bool sweep_rl_enabled() {
     static const int on = [] {
@@ -2455,9 +2455,7 @@ void launch_sweep(unsigned grid, hipStream_t st, const double* G, double* F, dou
         k_sweep_rl<N, FUSED, 9><<<grid + 1, 256, 0, st>>>(G, F, Linv, ld, CB, RT, flags, info, ctr, dd, hs, lenient);
     else if (sweep_rl_enabled() && CB <= 17)
         k_sweep_rl<N, FUSED, 17><<<grid + 1, 256, 0, st>>>(G, F, Linv, ld, CB, RT, flags, info, ctr, dd, hs, lenient);
-    else if (sweep_rl_enabled() && CB <= 33)
-        k_sweep_rl<N, FUSED, 33><<<grid + 1, 256, 0, st>>>(G, F, Linv, ld, CB, RT, flags, info, ctr, dd, hs, lenient);
-    else
+    else  // (a 33-tile row block no longer fits the register file: measured 1280 us against 666 at N = 1024)
         k_sweep<N, FUSED><<<grid, 256, 0, st>>>(G, F, Linv, ld, CB, RT, flags, info, ctr, dd, claim, hs, lenient);
 }
 
@@ -2718,7 +2716,7 @@ int run_cov_sqrtm_sweep(pnmol_filter* f, const double* Gc, double* Fc, double* L
     DowndateArgs dd{};
     const int cb = Dq / NB;
     launch_sweep<N, false>(cb, f->ctx->stream, Gc, Fc, Linvc, Dq, cb, cb, f->flags, f->info_err, f->one, dd,
-                           f->flags + 2 * cb + 1, cb <= 33 && sweep_rl_enabled() ? feedc : f->hs_scratch, 1);
+                           f->flags + 2 * cb + 1, cb <= 17 && sweep_rl_enabled() ? feedc : f->hs_scratch, 1);
     return 0;
 }
 
