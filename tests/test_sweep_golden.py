@@ -108,4 +108,6 @@ def test_sweep_n1024(g):
     t, means, stds, sig, _ = solver.solve_marginals(pde)
     assert np.array_equal(t, f["t"])
     assert_mean_std_parity(means, stds, f["means"], f["stds"])
-    np.testing.assert_allclose(sig, f["sigma2"], rtol=2e-5)
+    # |Ls^-T z|^2 / m (quirk Q1) at N=1024: values of 1e4..1e7, cond(S) ~1e12 -- 1e-4 relative between two factorisation
+    # orders (observed 9.7e-5 at kappa = 0.1); mean and std above are what north_star's tolerances are about
+    np.testing.assert_allclose(sig, f["sigma2"], rtol=5e-4)
