@@ -18,7 +18,8 @@
  *     reference's `PDEFilterState` carries.
  *   - one ctx <-> one device <-> one HIP stream.  A ctx is not thread-safe; different
  *     ctxs are independent (one thread or process per GPU).
- *   - dtype: fp64 (the reference runs with jax_enable_x64, src/pnmol/__init__.py:9-11).
+ *   - dtype: fp64 (the reference runs with jax_enable_x64, src/pnmol/__init__.py:9-11); `pnmol_filter_desc.dtype = 1`
+ *     keeps the covariance and its bulk kernels in fp32 (build-side option).
  */
 #ifndef PNMOL_HIP_H
 #define PNMOL_HIP_H
@@ -58,6 +59,14 @@ typedef struct pnmol_filter_desc {
                               (2d, 2d) = blockdiag(chol K, E_sqrtm) (latent.py:136-153), E_sqrtm/R_sqrtm are the
                               measurement noise factors (zero: update_sqrt_no_meascov, latent.py:197).  State
                               buffers are then (n, 2d) / (2D, 2D) in the reference's glued order (latent.py:163-175). */
+    int dtype;             /* 0: fp64 (the reference's arithmetic, src/pnmol/__init__.py:9-11).
+                              1: fp32 covariance (BASELINE config 5's "fp32 with tolerance study"): the state
+                              covariance, the predicted covariance and Q live in HBM as fp32, and the bulk of the step --
+                              P- = A P A^T + Q, the stencil gather P- H^T, the down-date P = P- - W W^T (fp32 MFMA,
+                              v_mfma_f32_16x16x4_f32) -- runs on them; the stencil weights, S = H P- H^T + R, its Cholesky
+                              sweep (Ls, W, r), the mean and every scalar stay fp64.  Buffers crossing this boundary are
+                              double either way.  Needs num_derivatives <= 2.  What it costs in accuracy: DESIGN.md
+                              section 11 (tolerance study). */
 } pnmol_filter_desc;
 
 int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_filter** out);

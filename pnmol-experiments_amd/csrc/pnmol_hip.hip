@@ -79,8 +79,10 @@ __device__ __forceinline__ void h_row_load(const MeasModel& mm, int i, HRow& r) 
     }
 }
 
-// (H x)[i] for a state-indexed vector x (global or LDS)
-__device__ __forceinline__ double h_row_dot(const MeasModel& mm, int i, const double* x) {
+// (H x)[i] for a state-indexed vector x (global or LDS).  XT = double, or float for a row of an fp32 covariance
+// (pnmol_filter_desc.dtype): the stencil weights and the accumulation stay fp64 ("L assembled in fp64").
+template <typename XT>
+__device__ __forceinline__ double h_row_dot(const MeasModel& mm, int i, const XT* x) {
     double v = 0.0;
     if (i < mm.d) v = mm.c1 * x[mm.dp + i];
     for (int e = 0; e < mm.w; ++e) {
@@ -91,8 +93,8 @@ __device__ __forceinline__ double h_row_dot(const MeasModel& mm, int i, const do
 }
 
 // same value (same summation order: derivative-1 term first, then the stencil entries) from a preloaded row
-template <int W>
-__device__ __forceinline__ double h_row_dot_w(const HRow& r, const double* __restrict__ x) {
+template <int W, typename XT>
+__device__ __forceinline__ double h_row_dot_w(const HRow& r, const XT* __restrict__ x) {
     double xv[W + 1];
 #pragma unroll
     for (int e = 0; e <= W; ++e) xv[e] = x[r.idx[e]];
@@ -151,24 +153,10 @@ __device__ __forceinline__ void predict_vectors(double* mpl, int tid, const IwpC
 // (into the z row of G and zbuf) and advances the step counter: every later kernel of this step writes its
 // per-step outputs to slot *ctr - 1, so all steps launch with identical arguments (hipGraph replay).
 // ------------------------------------------------------------------------------------------
-template <int N>
-__global__ __launch_bounds__(256) void k_predict(const double* __restrict__ Pin, double* __restrict__ Pout,
-                                                 const double* __restrict__ Kg, IwpConsts c, int dp,
-                                                 const double* __restrict__ min, double* __restrict__ mpred,
-                                                 const double* __restrict__ shift, double* __restrict__ G,
-                                                 double* __restrict__ zbuf, MeasModel mm, int* __restrict__ ctr,
-                                                 int* __restrict__ flags, int nflags) {
+template <int N, typename PT>
+__device__ __forceinline__ void predict_tile(const PT* __restrict__ Pin, PT* __restrict__ Pout, const double* __restrict__ Kg,
+                                             const IwpConsts& c, int dp, int j, int k) {
     const long Dp = (long)N * dp;
-    if (blockIdx.y == 0) {  // dispatched first, so its short dependent-load chain hides behind the tile blocks
-        if (blockIdx.x != 0) return;
-        extern __shared__ double mpl[];  // predicted mean, Dp doubles
-        const int tid = threadIdx.y * 32 + threadIdx.x;
-        predict_vectors<N>(mpl, tid, c, dp, min, mpred, shift, G, zbuf, mm, flags, nflags);
-        if (tid == 0) *ctr += 1;
-        return;
-    }
-    const int k = blockIdx.x * 32 + threadIdx.x;
-    const int j = (blockIdx.y - 1) * 8 + threadIdx.y;
     double X[N][N];
 #pragma unroll
     for (int a = 0; a < N; ++a)
@@ -192,13 +180,36 @@ __global__ __launch_bounds__(256) void k_predict(const double* __restrict__ Pin,
             double sacc = c.Q1[a * MAXN + b] * kjk;
 #pragma unroll
             for (int e = 0; e < N; ++e) sacc += T[a][e] * c.A1[b * MAXN + e];
-            Pout[((long)a * dp + j) * Dp + (long)b * dp + k] = sacc;
+            Pout[((long)a * dp + j) * Dp + (long)b * dp + k] = (PT)sacc;
         }
+}
+
+// p32: the covariance is stored in fp32 (pnmol_filter_desc.dtype = 1); the n x n block transform itself is done in fp64
+template <int N>
+__global__ __launch_bounds__(256) void k_predict(const void* __restrict__ Pin, void* __restrict__ Pout,
+                                                 const double* __restrict__ Kg, IwpConsts c, int dp,
+                                                 const double* __restrict__ min, double* __restrict__ mpred,
+                                                 const double* __restrict__ shift, double* __restrict__ G,
+                                                 double* __restrict__ zbuf, MeasModel mm, int* __restrict__ ctr,
+                                                 int* __restrict__ flags, int nflags, int p32) {
+    if (blockIdx.y == 0) {  // dispatched first, so its short dependent-load chain hides behind the tile blocks
+        if (blockIdx.x != 0) return;
+        extern __shared__ double mpl[];  // predicted mean, Dp doubles
+        const int tid = threadIdx.y * 32 + threadIdx.x;
+        predict_vectors<N>(mpl, tid, c, dp, min, mpred, shift, G, zbuf, mm, flags, nflags);
+        if (tid == 0) *ctr += 1;
+        return;
+    }
+    const int k = blockIdx.x * 32 + threadIdx.x;
+    const int j = (blockIdx.y - 1) * 8 + threadIdx.y;
+    if (p32) predict_tile<N>(static_cast<const float*>(Pin), static_cast<float*>(Pout), Kg, c, dp, j, k);
+    else predict_tile<N>(static_cast<const double*>(Pin), static_cast<double*>(Pout), Kg, c, dp, j, k);
 }
 
 // S[ip, i] = (H P- H^T)[ip, i] + R[ip, i] straight from P- (identity on the padding).  Same association order as
 // H (P- H^T): inner sum over the stencil of column i, outer sum over the stencil of row ip.
-__device__ __forceinline__ double s_entry(const double* __restrict__ Ppred, long Dp, const MeasModel& mm, int ip, int i,
+template <typename PT>
+__device__ __forceinline__ double s_entry(const PT* __restrict__ Ppred, long Dp, const MeasModel& mm, int ip, int i,
                                           const double* __restrict__ rdiag, const double* __restrict__ Rdense) {
     if (ip >= mm.m || i >= mm.m) return (ip == i) ? 1.0 : 0.0;
     double v = 0.0;
@@ -213,8 +224,8 @@ __device__ __forceinline__ double s_entry(const double* __restrict__ Ppred, long
 }
 
 // stencil width <= W: all index loads, then all P- loads, are independent (pipelined) instead of 16 dependent gathers
-template <int W>
-__device__ __forceinline__ double s_entry_w(const double* __restrict__ Ppred, long Dp, const MeasModel& mm,
+template <int W, typename PT>
+__device__ __forceinline__ double s_entry_w(const PT* __restrict__ Ppred, long Dp, const MeasModel& mm,
                                             const HRow& rrow /* row ip */, const HRow& rcol /* row i */, int ip, int i,
                                             const double* __restrict__ rdiag, const double* __restrict__ Rdense) {
     if (ip >= mm.m || i >= mm.m) return (ip == i) ? 1.0 : 0.0;
@@ -586,9 +597,15 @@ __device__ __forceinline__ void diag4_inverse_step(d4& w00, d4& w10, d4& w11, Di
 // (quadrant (1,0) of w2 is not used; quadrant (0,1) holds the transposed LOWER entries).  L->flag*: zero on entry.
 // Fd (leading dim ld): L, upper part zeroed.  Li: L^-1 (32x32; its upper-right quadrant is never written: the caller
 // keeps it zero).  Returns after this wave's part; w1 returns with its L^-1 stores issued, not drained.
+// `lenient` codes of the sweep kernels: 0 = strict (fp64 step), 1 = a non-positive pivot is a dropped direction, never an
+// error (Cholesky factor of a covariance that is PSD only up to rounding), 2 = the same for an fp32 covariance
+// (pnmol_filter_desc.dtype = 1), whose innovation matrix carries errors of 6e-8 |P-|: a pivot below 3e-6 of its diagonal
+// entry has lost all significance there.
+__device__ __forceinline__ double pivot_tolerance(int lenient) { return lenient == 2 ? 3e-6 : 1e-13; }
+
 // L itself (nobody inside the sweep reads a diagonal tile) and the info word, from the LDS record of a finished block
 __device__ __forceinline__ void diag4_output(Diag4Lds* L, int lane, double* __restrict__ Fd, long ld, int* info, int base,
-                                             const double* sd_blk, double smax) {
+                                             const double* sd_blk, double smax, double pivtol = 1e-13) {
     const int fr = lane & 15, fk = lane >> 4;
     lds_flag_wait(&L->flagA[7]);
     lds_flag_wait(&L->flagB[3]);
@@ -601,7 +618,7 @@ __device__ __forceinline__ void diag4_output(Diag4Lds* L, int lane, double* __re
     }
     if (lane < NB) {
         const double pv = L->piv[lane], sdv = fabs(sd_blk[lane]);
-        const bool fatal = !(pv > 1e-13 * sdv) && (!(pv == pv) || (pv < -1e-3 * sdv && sdv > 1e-12 * smax));
+        const bool fatal = !(pv > pivtol * sdv) && (!(pv == pv) || (pv < -1e-3 * sdv && sdv > 1e-12 * smax));
         const unsigned long long mk = __ballot(fatal);
         if (mk != 0 && lane == 0) atomicMin(info, base + __builtin_ctzll(mk));
     }
@@ -612,13 +629,13 @@ __device__ __forceinline__ void diag4_output(Diag4Lds* L, int lane, double* __re
 template <bool WT, bool TO_LDS = false, bool OUT2 = true, bool TO_GLOBAL = true>
 __device__ __forceinline__ void diag4_factor(const d4& nq, Diag4Lds* L, int w, int lane, double* __restrict__ Fd, long ld,
                                              double* __restrict__ Li, int* info, int base, const double* sd_blk, double smax,
-                                             double* sLinv = nullptr) {
+                                             double* sLinv = nullptr, double pivtol = 1e-13) {
     const int fr = lane & 15, fk = lane >> 4;
     if (w == 0) {
         d4 n = nq;
         double ind[10];
         diag4_indicators(ind, lane);
-        const double thrv = 1e-13 * fabs(sd_blk[fr]);
+        const double thrv = pivtol * fabs(sd_blk[fr]);
         diag4_step<0>(n, thrv, ind, lane, L->la[0], L->x0[0], L->piv + 0, &L->flagA[0]);
         diag4_step<1>(n, thrv, ind, lane, L->la[1], L->x0[1], L->piv + 4, &L->flagA[1]);
         diag4_step<2>(n, thrv, ind, lane, L->la[2], L->x0[2], L->piv + 8, &L->flagA[2]);
@@ -627,7 +644,7 @@ __device__ __forceinline__ void diag4_factor(const d4& nq, Diag4Lds* L, int w, i
         d4 n11 = nq, n01;
         double ind[10];
         diag4_indicators(ind, lane);
-        const double thrv = 1e-13 * fabs(sd_blk[16 + fr]);
+        const double thrv = pivtol * fabs(sd_blk[16 + fr]);
         lds_flag_wait(&L->flagN);
 #pragma unroll
         for (int r = 0; r < 4; ++r) n01[r] = L->n01[r][lane];
@@ -680,7 +697,7 @@ __device__ __forceinline__ void diag4_factor(const d4& nq, Diag4Lds* L, int w, i
             }
         }
     } else {  // w == 2
-        if constexpr (OUT2) diag4_output(L, lane, Fd, ld, info, base, sd_blk, smax);
+        if constexpr (OUT2) diag4_output(L, lane, Fd, ld, info, base, sd_blk, smax, pivtol);
     }
 }
 
@@ -710,7 +727,8 @@ __device__ __forceinline__ void tile_g2s(const double* __restrict__ g, long ld, 
 //   [Dp, Dp+mp)         row of S = H P- H^T + R             (straight from P-, see s_entry)
 //   [Dp+mp, Dp+2mp)     row of the trailing identity block  (the sweep turns it into Ls^-T)
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void front_block(const double* __restrict__ Ppred, double* __restrict__ G,
+template <typename PT>
+__device__ __forceinline__ void front_block(const PT* __restrict__ Ppred, double* __restrict__ G,
                                             const double* __restrict__ rdiag, const double* __restrict__ Rdense,
                                             const MeasModel& mm, long Dp, int bx, long y) {
     const int tid = threadIdx.x;
@@ -761,10 +779,11 @@ __global__ void k_set_identity(double* __restrict__ Gi, int mp) {
     if (q < mp) Gi[(long)q * mp + q] = 1.0;
 }
 
-__global__ __launch_bounds__(256) void k_front(const double* __restrict__ Ppred, double* __restrict__ G,
+__global__ __launch_bounds__(256) void k_front(const void* __restrict__ Ppred, double* __restrict__ G,
                                                const double* __restrict__ rdiag, const double* __restrict__ Rdense,
-                                               MeasModel mm, long Dp) {
-    front_block(Ppred, G, rdiag, Rdense, mm, Dp, blockIdx.x, blockIdx.y);
+                                               MeasModel mm, long Dp, int p32) {
+    if (p32) front_block(static_cast<const float*>(Ppred), G, rdiag, Rdense, mm, Dp, blockIdx.x, blockIdx.y);
+    else front_block(static_cast<const double*>(Ppred), G, rdiag, Rdense, mm, Dp, blockIdx.x, blockIdx.y);
 }
 
 // first diagonal block: diag(S) -> sdiag, its max -> sdiag[mp]; F[0,0] = chol(G[0,0]), Linv[0] = its inverse
@@ -1237,8 +1256,8 @@ __device__ __forceinline__ void vecops_rows4(const VecArgs& va, const double* __
 
 // Arguments of the covariance down-date role (workgroups RT .. RT + pairs - 1 of a fused launch)
 struct DowndateArgs {
-    const double* Ppred;  // P-  (Dp x Dp)
-    double* Pout;         // P = P- - W W^T
+    const void* Ppred;    // P-  (Dp x Dp), fp64 or (p32) fp32
+    void* Pout;           // P = P- - W W^T
     double* var;          // diag(P)
     int dp;               // padded points per derivative (multiple of 32)
     int vrows;            // rows of the vector ops (vecops_rows) each down-date workgroup does at its end
@@ -1246,18 +1265,39 @@ struct DowndateArgs {
     // constant-step loop: the epilogue also predicts the NEXT step's covariance, P-' = A P A^T + Q, in place of P-
     // (a lane holds all n x n derivative entries of its point pairs), so the loop's steps need no k_predict pass over
     // P; P itself is then only written by the step whose counter equals *last_ctr.
-    double* Pnext;        // = Ppred (in place: a workgroup only reads its own tile of P-, at its start) or nullptr
+    void* Pnext;          // = Ppred (in place: a workgroup only reads its own tile of P-, at its start) or nullptr
     const double* Kg;     // K = Gamma Gamma^T (dp x dp)
     const int* last_ctr;  // step counter value of the last step of the call
     double A1[MAXN * MAXN], Q1[MAXN * MAXN];
+    int p32;              // the covariance is fp32 (pnmol_filter_desc.dtype = 1): fp32 accumulators on v_mfma_f32_16x16x4_f32
+};
+
+// accumulator / MFMA of the down-date in the covariance's element type
+template <typename PT>
+struct AccOf;
+template <>
+struct AccOf<double> {
+    typedef d4 type;
+    static __device__ __forceinline__ d4 mfma_neg(double a, double b, d4 c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(-a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int fk, int r) { return fk + 4 * r; }  // C/D row of register r, lane group fk
+};
+template <>
+struct AccOf<float> {
+    typedef float type __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ type mfma_neg(double a, double b, type c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(-(float)a, (float)b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int fk, int r) { return 4 * fk + r; }  // (the f64 form is the odd one out)
 };
 
 // Down-date role: one workgroup per lower pair (J >= K) of 32-point tiles, all N x N derivative blocks.  Wave
 // (qr, qc) owns the 16x16 quadrant (qr, qc) of each block: its accumulators start as the P- tile, every 32-column
 // block j of W is subtracted as soon as the 2 N row blocks of W it needs have published step j (row[] counters), so
 // the down-date rides along with the sweep on CUs the sweep does not use instead of following it.
-template <int N>
-__device__ __forceinline__ void sweep_downdate_role(SweepLds& L, const DowndateArgs& dd, const double* F, int ld, int CB,
+template <int N, typename PT>
+__device__ __forceinline__ void sweep_downdate_body(SweepLds& L, const DowndateArgs& dd, const double* F, int ld, int CB,
                                                     int RBS, const int* frow, int* fabort, int* info, int pair, int tid,
                                                     int l, int w, int slot) {
     const int fr = l & 15, fk = l >> 4, qr = w >> 1, qc = w & 1;
@@ -1268,15 +1308,16 @@ __device__ __forceinline__ void sweep_downdate_role(SweepLds& L, const DowndateA
     const int K = pair - J * (J + 1) / 2;
     const long Dp = (long)N * dd.dp;
     const double* W = F + (long)ld * ld;  // rows of W follow the ld (= mp) rows of Ls
-    d4 acc[N][N];
+    typedef typename AccOf<PT>::type acc_t;
+    const PT* Ppred = static_cast<const PT*>(dd.Ppred);
+    acc_t acc[N][N];
 #pragma unroll
     for (int a = 0; a < N; ++a)
 #pragma unroll
         for (int b = 0; b < N; ++b)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                acc[a][b][r] = dd.Ppred[((long)a * dd.dp + J * NB + qr * 16 + fk + 4 * r) * Dp + (long)b * dd.dp + K * NB +
-                                        qc * 16 + fr];
+                acc[a][b][r] = Ppred[((long)a * dd.dp + J * NB + qr * 16 + AccOf<PT>::row(fk, r)) * Dp + (long)b * dd.dp + K * NB + qc * 16 + fr];
     int avail = 0;  // column blocks of W known to be complete for all 2 N row blocks
     for (int j = 0; j < CB; ++j) {
         if (j >= avail) {
@@ -1324,19 +1365,19 @@ __device__ __forceinline__ void sweep_downdate_role(SweepLds& L, const DowndateA
             for (int a = 0; a < N; ++a)
 #pragma unroll
                 for (int b = 0; b < N; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-fa[a].v[s], fb[b].v[s], acc[a][b], 0, 0, 0);
+                    acc[a][b] = AccOf<PT>::mfma_neg(fa[a].v[s], fb[b].v[s], acc[a][b]);
     }
     SWEEP_STAMP(1);
     // epilogue: the tile, diag(P), and (J != K) the mirror image, transposed through wave-private LDS so that it
     // leaves as 128-byte rows; in the constant-step loop also (or, except for the last step, instead) the next
     // step's predicted covariance
-    double* stg = L.sP[w];
+    PT* stg = reinterpret_cast<PT*>(L.sP[w]);
     const bool write_p = dd.Pnext == nullptr || (slot + 1 == *dd.last_ctr);
-    auto put_block = [&](double* dst, const d4& v, long row0, long col0) {
+    auto put_block = [&](PT* dst, const acc_t& v, long row0, long col0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            dst[(row0 + fk + 4 * r) * Dp + col0 + fr] = v[r];
-            if (J != K) stg[(fk + 4 * r) * 17 + fr] = v[r];
+            dst[(row0 + AccOf<PT>::row(fk, r)) * Dp + col0 + fr] = v[r];
+            if (J != K) stg[AccOf<PT>::row(fk, r) * 17 + fr] = v[r];
         }
         if (J != K) {
             __builtin_amdgcn_wave_barrier();
@@ -1352,35 +1393,35 @@ __device__ __forceinline__ void sweep_downdate_role(SweepLds& L, const DowndateA
         if (J == K && qr == qc) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (fk + 4 * r == fr) dd.var[row0 + fr] = acc[a][a][r];
+                if (AccOf<PT>::row(fk, r) == fr) dd.var[row0 + fr] = acc[a][a][r];
         }
         if (write_p) {
 #pragma unroll
-            for (int b = 0; b < N; ++b) put_block(dd.Pout, acc[a][b], row0, (long)b * dd.dp + K * NB + qc * 16);
+            for (int b = 0; b < N; ++b) put_block(static_cast<PT*>(dd.Pout), acc[a][b], row0, (long)b * dd.dp + K * NB + qc * 16);
         }
     }
     if (dd.Pnext) {  // P-' = A1 X A1^T + Q1 K[j,k] per point pair, X = the n x n entries this lane holds
-        d4 kjk;
+        acc_t kjk;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) kjk[r] = dd.Kg[(long)(J * NB + qr * 16 + fk + 4 * r) * dd.dp + K * NB + qc * 16 + fr];
-        d4 T[N][N];
+        for (int r = 0; r < 4; ++r) kjk[r] = (PT)dd.Kg[(long)(J * NB + qr * 16 + AccOf<PT>::row(fk, r)) * dd.dp + K * NB + qc * 16 + fr];
+        acc_t T[N][N];
 #pragma unroll
         for (int a = 0; a < N; ++a)
 #pragma unroll
             for (int e = 0; e < N; ++e) {
-                d4 t = {0, 0, 0, 0};
+                acc_t t = {0, 0, 0, 0};
 #pragma unroll
-                for (int q = 0; q < N; ++q) t += dd.A1[a * MAXN + q] * acc[q][e];
+                for (int q = 0; q < N; ++q) t += (PT)dd.A1[a * MAXN + q] * acc[q][e];
                 T[a][e] = t;
             }
 #pragma unroll
         for (int a = 0; a < N; ++a)
 #pragma unroll
             for (int b = 0; b < N; ++b) {
-                d4 pn = dd.Q1[a * MAXN + b] * kjk;
+                acc_t pn = (PT)dd.Q1[a * MAXN + b] * kjk;
 #pragma unroll
-                for (int e = 0; e < N; ++e) pn += T[a][e] * dd.A1[b * MAXN + e];
-                put_block(dd.Pnext, pn, (long)a * dd.dp + J * NB + qr * 16, (long)b * dd.dp + K * NB + qc * 16);
+                for (int e = 0; e < N; ++e) pn += T[a][e] * (PT)dd.A1[b * MAXN + e];
+                put_block(static_cast<PT*>(dd.Pnext), pn, (long)a * dd.dp + J * NB + qr * 16, (long)b * dd.dp + K * NB + qc * 16);
             }
     }
     SWEEP_STAMP(2);
@@ -1412,6 +1453,14 @@ __device__ __forceinline__ void sweep_downdate_role(SweepLds& L, const DowndateA
     }
     if (tid == 0 && L.dead) atomicMin(info, -2);
     SWEEP_STAMP(5);
+}
+
+template <int N>
+__device__ __forceinline__ void sweep_downdate_role(SweepLds& L, const DowndateArgs& dd, const double* F, int ld, int CB,
+                                                    int RBS, const int* frow, int* fabort, int* info, int pair, int tid,
+                                                    int l, int w, int slot) {
+    if (dd.p32) sweep_downdate_body<N, float>(L, dd, F, ld, CB, RBS, frow, fabort, info, pair, tid, l, w, slot);
+    else sweep_downdate_body<N, double>(L, dd, F, ld, CB, RBS, frow, fabort, info, pair, tid, l, w, slot);
 }
 
 template <int N, bool FUSED, bool CHAINHELP = FUSED>
@@ -1638,7 +1687,7 @@ __global__ __launch_bounds__(256) void k_sweep(const double* __restrict__ G, dou
         __hip_atomic_store(&L.pub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     diag4_factor<true>(accD, &L.d4, w, l, F + ((long)I * NB) * ld + (long)I * NB, ld, Linv + (long)I * NB * NB, info, I * NB,
-                       L.sd, smax);
+                       L.sd, smax, nullptr, pivot_tolerance(lenient));
     if (w == 1) {
         drain_vmem();  // L^-1 has reached memory
         if (I > 0) {
@@ -1796,6 +1845,7 @@ __device__ __forceinline__ void sweep_chain_role(ChainLds& C, const double* __re
     if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __syncthreads();
     smax = lenient ? __builtin_inf() : fmax(fmax(C.red[0], C.red[1]), fmax(C.red[2], C.red[3]));
+    const double pivtol = pivot_tolerance(lenient);
     d4 accD;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {  // quadrant of -G_00, lower entries only
@@ -1807,9 +1857,9 @@ __device__ __forceinline__ void sweep_chain_role(ChainLds& C, const double* __re
         CHAIN_TRACE(J, 0);
         if (w == 2 && J > 0)  // L_{J-1,J-1} and its pivots, off the critical path
             diag4_output(&C.d4[(J - 1) & 1], l, F + ((long)(J - 1) * NB) * ld + (long)(J - 1) * NB, ld, info, (J - 1) * NB,
-                         C.sd[(J - 1) & 1], smax);
+                         C.sd[(J - 1) & 1], smax, pivtol);
         diag4_factor<true, true, false, false>(accD, dl, w, l, F + ((long)J * NB) * ld + (long)J * NB, ld,
-                                               Linv + (long)J * NB * NB, info, J * NB, C.sd[J & 1], smax, C.sLinv);
+                                               Linv + (long)J * NB * NB, info, J * NB, C.sd[J & 1], smax, C.sLinv, pivtol);
         CHAIN_TRACE_W(J, 1, 3);
         CHAIN_TRACE_W(J, 6, 1);
         // w1 has left L^-1 in C.sLinv.  w2 publishes it behind the next block's TRSM: the other row blocks need it, the
@@ -1863,7 +1913,7 @@ __device__ __forceinline__ void sweep_chain_role(ChainLds& C, const double* __re
     }
     if (w == 2)
         diag4_output(&C.d4[(CB - 1) & 1], l, F + ((long)(CB - 1) * NB) * ld + (long)(CB - 1) * NB, ld, info, (CB - 1) * NB,
-                     C.sd[(CB - 1) & 1], smax);
+                     C.sd[(CB - 1) & 1], smax, pivtol);
     if (l == 0 && ww.dead) atomicMin(info, -2);
 }
 
@@ -2248,14 +2298,16 @@ __global__ __launch_bounds__(256, (N <= 3 ? 4 : 1)) void k_downdate(const double
 // a filter whose predicted covariance is Q = Q1 (x) K, so the same k_front / k_sweep pair factorises it:
 // [Sq; I] -> [Lq; Lq^-T], and Sq^-1 = Lq^-T Lq^-1.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fill_q(double* __restrict__ Qf, const double* __restrict__ Kg, IwpConsts c, int n,
-                                                int dp) {
+__global__ __launch_bounds__(256) void k_fill_q(void* __restrict__ Qf, const double* __restrict__ Kg, IwpConsts c, int n,
+                                                int dp, int p32) {
     const long Dp = (long)n * dp;
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= Dp * Dp) return;
     const long row = e / Dp, col = e % Dp;
     const int a = (int)(row / dp), j = (int)(row % dp), b = (int)(col / dp), k = (int)(col % dp);
-    Qf[e] = c.Q1[a * MAXN + b] * Kg[(long)j * dp + k];
+    const double v = c.Q1[a * MAXN + b] * Kg[(long)j * dp + k];
+    if (p32) static_cast<float*>(Qf)[e] = (float)v;
+    else static_cast<double*>(Qf)[e] = v;
 }
 
 // C = T T^T for a row-major (mp x mp) T (rows dot rows), 16x16 outputs per workgroup
@@ -2283,14 +2335,15 @@ __global__ __launch_bounds__(256) void k_readout(const double* __restrict__ mean
                                                  double s0, int d, const double* __restrict__ part,
                                                  double* __restrict__ rec_base, int mp, int* __restrict__ ctr,
                                                  RoleArgs ra, int* __restrict__ tickets, int rblocks,
-                                                 const double* __restrict__ Ppred, const double* __restrict__ rdiag,
-                                                 const double* __restrict__ Rdense) {
+                                                 const void* __restrict__ Ppred, const double* __restrict__ rdiag,
+                                                 const double* __restrict__ Rdense, int p32) {
     if constexpr (ROLE) {
         // blocks behind the read-out and role blocks: the NEXT step's k_front (G from the P- the down-date epilogue
         // has just written) -- independent of the rest of this launch, which hides behind it
         if ((int)blockIdx.x > rblocks) {
             const int fb = blockIdx.x - rblocks - 1, gx = (mp + 255) / 256;
-            front_block(Ppred, ra.G, rdiag, Rdense, ra.mm, (long)N * ra.dp, fb % gx, fb / gx);
+            if (p32) front_block(static_cast<const float*>(Ppred), ra.G, rdiag, Rdense, ra.mm, (long)N * ra.dp, fb % gx, fb / gx);
+            else front_block(static_cast<const double*>(Ppred), ra.G, rdiag, Rdense, ra.mm, (long)N * ra.dp, fb % gx, fb / gx);
             return;
         }
     }
@@ -2376,6 +2429,8 @@ struct pnmol_filter {
     int sweep_mode = 2;    // PNMOL_HIP_SWEEP: 2 = k_sweep with the covariance down-date riding along in the same launch,
                            // 1 = k_sweep, then k_downdate; 0 = k_diag0 + one k_panel launch per panel, then k_downdate
     int ds = 0;  // spatial components of the state (= d, or 2d for the latent-force model [u; eps])
+    int p32 = 0;        // pnmol_filter_desc.dtype = 1: covariances (state, predicted, Q) are stored and down-dated in fp32
+    size_t psz = 8;     // bytes per covariance element
     long Dp = 0;
     IwpConsts iwp{};
     int* ell_col = nullptr;
@@ -2479,17 +2534,17 @@ int launch_step(pnmol_filter* f, const double* Pin, const double* min, double fr
     //  k_readout launch did the vector part)
     if (kind != STEP_STEADY)
         k_predict<N><<<dim3(dp / 32, dp / 8 + 1), dim3(32, 8), sizeof(double) * Dp, st>>>(
-        Pin, f->Ppred, f->Kg, c, dp, min, f->mpred, f->shift, f->G, f->zbuf, mm, f->ctr, f->flags, f->nflags);
+        Pin, f->Ppred, f->Kg, c, dp, min, f->mpred, f->shift, f->G, f->zbuf, mm, f->ctr, f->flags, f->nflags, f->p32);
     // K2: G = [S; P-H^T; z; I]  (STEADY: done by the previous step's k_readout launch)
     if (kind != STEP_STEADY)
         k_front<<<dim3((mp + 255) / 256, (unsigned)(Dp + mp + (f->sweep_mode == 0 ? mp : 0))), 256, 0, st>>>(
-            f->Ppred, f->G, f->rdiag, f->Rdense, mm, Dp);  // (the per-panel path updates G in place: identity block too)
+            f->Ppred, f->G, f->rdiag, f->Rdense, mm, Dp, f->p32);  // (the per-panel path updates G in place: identity block too)
     const long rowI0 = (long)mp + Dp + NB;
     const double* W = f->F + (long)mp * mp;
     const bool have_sq = (f->Sqinv != nullptr && f->sq_dt == dt);
     VecArgs va{f->mpred, f->F + ((long)mp + Dp) * mp, f->F + rowI0 * mp, f->zbuf, have_sq ? f->Sqinv : nullptr,
                mout, f->part};
-    DowndateArgs dd{f->Ppred, Pout, varout, dp, 0, va, kind == STEP_FULL ? nullptr : f->Ppred, f->Kg, f->last_ctr, {}, {}};
+    DowndateArgs dd{f->Ppred, Pout, varout, dp, 0, va, kind == STEP_FULL ? nullptr : f->Ppred, f->Kg, f->last_ctr, {}, {}, f->p32};
     std::memcpy(dd.A1, f->iwp.A1, sizeof(dd.A1));
     std::memcpy(dd.Q1, f->iwp.Q1, sizeof(dd.Q1));
     if (f->sweep_mode == 2) {
@@ -2499,7 +2554,7 @@ int launch_step(pnmol_filter* f, const double* Pin, const double* min, double fr
         dd.vrows = 0;  // (the vector ops are done by the row-block workgroups of the sweep themselves)
         if constexpr (N <= 3)
             launch_sweep<N, true>(f->RT + pairs, st, f->G, f->F, f->Linv, mp, f->CB, f->RT, f->flags, f->info, f->ctr, dd,
-                                  f->flags + f->RT + f->CB + 1, f->hs_scratch, 0);
+                                  f->flags + f->RT + f->CB + 1, f->hs_scratch, f->p32 ? 2 : 0);
     } else {
         if (f->sweep_mode == 1) {
             // K3': the sweep alone as one dataflow launch
@@ -2528,11 +2583,11 @@ int launch_step(pnmol_filter* f, const double* Pin, const double* min, double fr
         k_readout<N, false><<<rblocks, 256, 0, st>>>(mout, varout, record ? f->rec_means : nullptr,
                                                     record ? f->rec_stds : nullptr, nordsieck_scale(f->nu, 0, dt), f->d,
                                                     f->part, f->rec, mp, f->ctr, ra, f->tickets, (int)rblocks, f->Ppred, f->rdiag,
-                                                    f->Rdense);
+                                                    f->Rdense, f->p32);
     else  // + the next step's vector predict (1 block) and k_front ((mp/256 rounded up) x (Dp + mp) blocks)
         k_readout<N, true><<<rblocks + 1 + (unsigned)(((mp + 255) / 256) * (Dp + mp)), 256, sizeof(double) * Dp, st>>>(
             mout, varout, record ? f->rec_means : nullptr, record ? f->rec_stds : nullptr, nordsieck_scale(f->nu, 0, dt),
-            f->d, f->part, f->rec, mp, f->ctr, ra, f->tickets, (int)rblocks, f->Ppred, f->rdiag, f->Rdense);
+            f->d, f->part, f->rec, mp, f->ctr, ra, f->tickets, (int)rblocks, f->Ppred, f->rdiag, f->Rdense, f->p32);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         ctx->err = std::string("kernel launch: ") + hipGetErrorString(e);
@@ -2639,15 +2694,16 @@ int prepare_graphs(pnmol_filter* f, pnmol_state* s, int k, double dt, hipGraphEx
 
 // Covariance in the reference's state order (index j n + a, raw coordinates) as a (Dq x Dq) matrix padded with the
 // identity: input of the on-device Cholesky behind pnmol_state_get_cov_sqrtm.
-__global__ __launch_bounds__(256) void k_cov_reference_order(const double* __restrict__ P, double* __restrict__ Gc, int n,
-                                                             int d, int dp, long Dq, const double* __restrict__ sc) {
+__global__ __launch_bounds__(256) void k_cov_reference_order(const void* __restrict__ P, double* __restrict__ Gc, int n,
+                                                             int d, int dp, long Dq, const double* __restrict__ sc, int p32) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= Dq * Dq) return;
     const long r = e / Dq, c = e % Dq, D = (long)n * d, Dp = (long)n * dp;
     double v = (r == c) ? 1.0 : 0.0;
     if (r < D && c < D) {
         const int j = (int)(r / n), a = (int)(r % n), k = (int)(c / n), b = (int)(c % n);
-        v = sc[a] * sc[b] * P[((long)a * dp + j) * Dp + (long)b * dp + k];
+        const long idx = ((long)a * dp + j) * Dp + (long)b * dp + k;
+        v = sc[a] * sc[b] * (p32 ? (double)static_cast<const float*>(P)[idx] : static_cast<const double*>(P)[idx]);
     }
     Gc[e] = v;
 }
@@ -2726,10 +2782,10 @@ int run_error_model_sweep(pnmol_filter* f, const MeasModel& mm) {
     const int mp = f->mp;
     const long Dp = f->Dp;
     k_front<<<dim3((mp + 255) / 256, (unsigned)(Dp + mp + (f->sweep_mode == 0 ? mp : 0))), 256, 0, st>>>(f->Qfull, f->G, f->rdiag,
-                                                                                                         f->Rdense, mm, Dp);
+                                                                                                         f->Rdense, mm, Dp, f->p32);
     DowndateArgs dd{};
     launch_sweep<N, false>(f->RT, st, f->G, f->F, f->Linv, mp, f->CB, f->RT, f->flags, f->info_err, f->one, dd,
-                           f->flags + f->RT + f->CB + 1, f->hs_scratch, 0);
+                           f->flags + f->RT + f->CB + 1, f->hs_scratch, f->p32 ? 2 : 0);
     return 0;
 }
 
@@ -2796,6 +2852,7 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
     pnmol_filter* f = new pnmol_filter();
     f->ctx = ctx;
     f->d = d, f->ds = ds, f->nu = nu, f->n = n, f->nB = nB, f->m = d + nB;
+    f->p32 = desc->dtype == 1, f->psz = f->p32 ? 4 : 8;
     f->dp = round_up(ds, NB), f->mp = round_up(f->m, NB);
     f->Dp = (long)n * f->dp;
     f->CB = f->mp / NB, f->RBS = f->mp / NB, f->RBW = (int)(f->Dp / NB), f->RT = f->RBS + f->RBW + 1 + f->RBS;  // [S; W; z-block; I]
@@ -2886,8 +2943,8 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
     FCHK(hipMalloc(&f->F, sizeof(double) * tall));
     FCHK(hipMalloc(&f->Linv, sizeof(double) * (size_t)f->CB * NB * NB));
     FCHK(hipMemset(f->Linv, 0, sizeof(double) * (size_t)f->CB * NB * NB));  // (upper-right quadrants stay zero: diag4_factor)
-    FCHK(hipMalloc(&f->Ppred, sizeof(double) * (size_t)Dp * Dp));
-    FCHK(hipMalloc(&f->tmpP, sizeof(double) * (size_t)Dp * Dp));
+    FCHK(hipMalloc(&f->Ppred, f->psz * (size_t)Dp * Dp));
+    FCHK(hipMalloc(&f->tmpP, f->psz * (size_t)Dp * Dp));
     FCHK(hipMalloc(&f->mpred, sizeof(double) * Dp));
     FCHK(hipMalloc(&f->tmpMean, sizeof(double) * Dp));
     FCHK(hipMalloc(&f->var, sizeof(double) * Dp));
@@ -2910,6 +2967,10 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
     FCHK(hipMalloc(&f->tickets, sizeof(int)));
     FCHK(hipMemset(f->tickets, 0, sizeof(int)));
     if (f->sweep_mode == 2 && n > 3) f->sweep_mode = 1;  // the fused down-date role is built for n <= 3
+    if (f->p32 && f->sweep_mode != 2) {
+        ctx->err = "pnmol_filter_create: dtype = fp32 covariance needs the fused sweep (num_derivatives <= 2, PNMOL_HIP_SWEEP unset)";
+        return fail(-1);
+    }
     FCHK(hipMemcpy(f->ell_col, ecol.data(), sizeof(int) * ecol.size(), hipMemcpyHostToDevice));
     FCHK(hipMemcpy(f->ell_val, eval.data(), sizeof(double) * eval.size(), hipMemcpyHostToDevice));
     FCHK(hipMemcpy(f->Kg, Kg.data(), sizeof(double) * Kg.size(), hipMemcpyHostToDevice));
@@ -2924,7 +2985,7 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
     FCHK(hipDeviceSynchronize());
     FCHK(hipMemset(f->F, 0, sizeof(double) * tall));
     FCHK(hipMemset(f->var, 0, sizeof(double) * Dp));
-    FCHK(hipMemset(f->tmpP, 0, sizeof(double) * (size_t)Dp * Dp));
+    FCHK(hipMemset(f->tmpP, 0, f->psz * (size_t)Dp * Dp));
     FCHK(hipMemset(f->tmpMean, 0, sizeof(double) * Dp));
     FCHK(hipEventCreate(&f->ev0));
     FCHK(hipEventCreate(&f->ev1));
@@ -2985,12 +3046,12 @@ int pnmol_filter_prepare_error_model(pnmol_filter* f, double dt) {
     const int mp = f->mp, m = f->m, dp = f->dp;
     const long Dp = f->Dp;
     if (!f->Qfull) {
-        HIPCHK(ctx, hipMalloc(&f->Qfull, sizeof(double) * (size_t)Dp * Dp));
+        HIPCHK(ctx, hipMalloc(&f->Qfull, f->psz * (size_t)Dp * Dp));
         HIPCHK(ctx, hipMalloc(&f->one, sizeof(int)));
         HIPCHK(ctx, hipMalloc(&f->info_err, sizeof(int)));
         const int h1 = 1;
         HIPCHK(ctx, hipMemcpy(f->one, &h1, sizeof(int), hipMemcpyHostToDevice));
-        k_fill_q<<<(unsigned)((Dp * Dp + 255) / 256), 256, 0, st>>>(f->Qfull, f->Kg, f->iwp, f->n, dp);
+        k_fill_q<<<(unsigned)((Dp * Dp + 255) / 256), 256, 0, st>>>(f->Qfull, f->Kg, f->iwp, f->n, dp, f->p32);
     }
     const bool fresh = (f->Sqinv == nullptr);
     if (fresh) HIPCHK(ctx, hipMalloc(&f->Sqinv, sizeof(double) * (size_t)mp * mp));
@@ -3084,14 +3145,14 @@ int pnmol_state_create(pnmol_filter* f, pnmol_state** out) {
     s->f = f;
     const size_t Dp = (size_t)f->Dp;
     if (hipMalloc(&s->mean, sizeof(double) * Dp) != hipSuccess || hipMalloc(&s->var, sizeof(double) * Dp) != hipSuccess ||
-        hipMalloc(&s->P, sizeof(double) * Dp * Dp) != hipSuccess) {
+        hipMalloc(&s->P, f->psz * Dp * Dp) != hipSuccess) {
         ctx->err = "pnmol_state_create: hipMalloc failed";
         pnmol_state_destroy(s);
         return -4;
     }
     hipMemset(s->mean, 0, sizeof(double) * Dp);
     hipMemset(s->var, 0, sizeof(double) * Dp);
-    hipMemset(s->P, 0, sizeof(double) * Dp * Dp);
+    hipMemset(s->P, 0, f->psz * Dp * Dp);
     *out = s;
     return 0;
 }
@@ -3115,7 +3176,7 @@ int pnmol_state_clone(const pnmol_state* s, pnmol_state** out) {
     const size_t Dp = (size_t)s->f->Dp;
     HIPCHK(ctx, hipMemcpyAsync(o->mean, s->mean, sizeof(double) * Dp, hipMemcpyDeviceToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(o->var, s->var, sizeof(double) * Dp, hipMemcpyDeviceToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(o->P, s->P, sizeof(double) * Dp * Dp, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(o->P, s->P, s->f->psz * Dp * Dp, hipMemcpyDeviceToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     o->t = s->t, o->frame_dt = s->frame_dt;
     return 0;
@@ -3144,7 +3205,12 @@ int pnmol_state_set(pnmol_state* s, double t, const double* mean_nd, const doubl
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipMemcpy(s->mean, hm.data(), sizeof(double) * hm.size(), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(s->var, hv.data(), sizeof(double) * hv.size(), hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(s->P, hP.data(), sizeof(double) * hP.size(), hipMemcpyHostToDevice));
+    if (f->p32) {
+        std::vector<float> hPf(hP.begin(), hP.end());
+        HIPCHK(ctx, hipMemcpy(s->P, hPf.data(), sizeof(float) * hPf.size(), hipMemcpyHostToDevice));
+    } else {
+        HIPCHK(ctx, hipMemcpy(s->P, hP.data(), sizeof(double) * hP.size(), hipMemcpyHostToDevice));
+    }
     s->t = t;
     s->frame_dt = 0.0;
     return 0;
@@ -3154,8 +3220,8 @@ namespace {
 // P = C C^T written straight into the state's derivative-major padded layout, C (D x D, any square root) in the
 // reference's F-flattened order: P[(a dp + j)(Dp) + (b dp + k)] = sum_c C[j n + a][c] C[k n + b][c].  One 32x32 tile of
 // points (j, k) for one derivative pair (a, b) per block, on the MFMA; also the marginal variances.
-__global__ __launch_bounds__(256) void k_cct_layout(double* __restrict__ P, double* __restrict__ var,
-                                                    const double* __restrict__ C, int d, int n, int dp, long Dp) {
+__global__ __launch_bounds__(256) void k_cct_layout(void* __restrict__ P, double* __restrict__ var,
+                                                    const double* __restrict__ C, int d, int n, int dp, long Dp, int p32) {
     __shared__ double sA[32][33], sB[32][33];
     const int t = threadIdx.x, w = t >> 6, lane = t & 63, fr = lane & 15, fk = lane >> 4, wr = w >> 1, wc = w & 1;
     const int tx = t & 31, ty = t >> 5;
@@ -3179,7 +3245,9 @@ __global__ __launch_bounds__(256) void k_cct_layout(double* __restrict__ P, doub
     for (int r = 0; r < 4; ++r) {
         const int j = j0 + wr * 16 + fk + 4 * r, k = k0 + wc * 16 + fr;
         if (j < d && k < d) {
-            P[((long)a * dp + j) * Dp + (long)b * dp + k] = acc[r];
+            const long idx = ((long)a * dp + j) * Dp + (long)b * dp + k;
+            if (p32) static_cast<float*>(P)[idx] = (float)acc[r];
+            else static_cast<double*>(P)[idx] = acc[r];
             if (a == b && j == k) var[(long)a * dp + j] = acc[r];
         }
     }
@@ -3203,10 +3271,10 @@ int pnmol_state_set_sqrtm(pnmol_state* s, double t, const double* mean_nd, const
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = -2; break; }
         if (hipMemcpy(s->mean, hm.data(), sizeof(double) * hm.size(), hipMemcpyHostToDevice) != hipSuccess) { rc = -2; break; }
         if (hipMemcpy(dC, cov_sqrtm_DD, sizeof(double) * (size_t)D * D, hipMemcpyHostToDevice) != hipSuccess) { rc = -2; break; }
-        if (hipMemsetAsync(s->P, 0, sizeof(double) * (size_t)Dp * Dp, ctx->stream) != hipSuccess) { rc = -2; break; }
+        if (hipMemsetAsync(s->P, 0, f->psz * (size_t)Dp * Dp, ctx->stream) != hipSuccess) { rc = -2; break; }
         if (hipMemsetAsync(s->var, 0, sizeof(double) * (size_t)Dp, ctx->stream) != hipSuccess) { rc = -2; break; }
-        hipLaunchKernelGGL(k_cct_layout, dim3((d + 31) / 32, (d + 31) / 32, n * n), dim3(256), 0, ctx->stream, s->P, s->var,
-                           dC, d, n, dp, Dp);
+        hipLaunchKernelGGL(k_cct_layout, dim3((d + 31) / 32, (d + 31) / 32, n * n), dim3(256), 0, ctx->stream, (void*)s->P, s->var,
+                           dC, d, n, dp, Dp, f->p32);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = -2; break; }
     } while (0);
     hipFree(dC);
@@ -3280,7 +3348,7 @@ int pnmol_state_get_cov_sqrtm(const pnmol_state* s, double* C_DD) {
         if (e == hipSuccess) e = hipMemsetAsync(f->flags, 0, sizeof(int) * f->nflags, st);
         if (e == hipSuccess) e = hipMemsetAsync(f->info_err, 0x7f, sizeof(int), st);
         if (e == hipSuccess) {
-            k_cov_reference_order<<<(unsigned)(((long)Dq * Dq + 255) / 256), 256, 0, st>>>(s->P, Gc, n, d, f->dp, Dq, dsc);
+            k_cov_reference_order<<<(unsigned)(((long)Dq * Dq + 255) / 256), 256, 0, st>>>(s->P, Gc, n, d, f->dp, Dq, dsc, f->p32);
             switch (n) {
                 case 2: run_cov_sqrtm_sweep<2>(f, Gc, Fc, Lc, Dq, feedc); break;
                 case 3: run_cov_sqrtm_sweep<3>(f, Gc, Fc, Lc, Dq, feedc); break;
@@ -3337,7 +3405,13 @@ int pnmol_state_get_cov(const pnmol_state* s, double* cov_DD) {
     const long D = (long)n * d, Dp = f->Dp;
     std::vector<double> hP((size_t)Dp * Dp);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    HIPCHK(ctx, hipMemcpy(hP.data(), s->P, sizeof(double) * hP.size(), hipMemcpyDeviceToHost));
+    if (f->p32) {
+        std::vector<float> hPf(hP.size());
+        HIPCHK(ctx, hipMemcpy(hPf.data(), s->P, sizeof(float) * hPf.size(), hipMemcpyDeviceToHost));
+        std::copy(hPf.begin(), hPf.end(), hP.begin());
+    } else {
+        HIPCHK(ctx, hipMemcpy(hP.data(), s->P, sizeof(double) * hP.size(), hipMemcpyDeviceToHost));
+    }
     double sc[MAXN];
     frame_scales(s, sc);
     for (int a = 0; a < n; ++a)
@@ -3510,7 +3584,7 @@ int pnmol_filter_prepare_steps(pnmol_filter* f, pnmol_state* s, int k, double dt
     if (rc != 0) return rc;
     // Rehearse the exact launch sequence once on the live buffers and restore them: graph capture,
     // instantiation and the runtime's first-launch work (tens of ms on ROCm 7.2) then happen here.
-    const size_t Dp = (size_t)f->Dp, nP = Dp * Dp;
+    const size_t Dp = (size_t)f->Dp, nP = Dp * Dp * f->psz / sizeof(double);  // (doubles the covariance occupies)
     double* bak = nullptr;
     HIPCHK(ctx, hipMalloc(&bak, sizeof(double) * (nP + 2 * Dp)));
     hipStream_t st = ctx->stream;
@@ -3572,6 +3646,12 @@ int pnmol_filter_debug_read(pnmol_filter* f, int which, double* dst, long count)
     }
     if (count > avail) return -1;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (which == 0 && f->p32) {  // fp32 covariance: widened for the caller
+        std::vector<float> h((size_t)count);
+        HIPCHK(ctx, hipMemcpy(h.data(), src, sizeof(float) * count, hipMemcpyDeviceToHost));
+        std::copy(h.begin(), h.end(), dst);
+        return 0;
+    }
     HIPCHK(ctx, hipMemcpy(dst, src, sizeof(double) * count, hipMemcpyDeviceToHost));
     return 0;
 }

@@ -40,6 +40,7 @@ class FilterDesc(ctypes.Structure):
         ("R_sqrtm", _c_double_p),
         ("Gamma", _c_double_p),
         ("d_state", ctypes.c_int),
+        ("dtype", ctypes.c_int),      # 0 fp64, 1 fp32 covariance (include/pnmol_hip.h)
     ]
 
 
@@ -214,13 +215,18 @@ class Context:
 class Filter:
     """`pnmol_filter`: the measurement/prior model of one discretised PDE on the device."""
 
-    def __init__(self, ctx, *, L, B, E_sqrtm, R_sqrtm, Gamma, num_derivatives):
+    DTYPES = {"f64": 0, "f32": 1}
+
+    def __init__(self, ctx, *, L, B, E_sqrtm, R_sqrtm, Gamma, num_derivatives, dtype="f64"):
+        """dtype "f32": the covariance and its bulk kernels (predict, H-apply, down-date) in fp32; the factorisation of
+        the innovation matrix, the mean and all scalars stay fp64 (`pnmol_filter_desc.dtype`)."""
         self.ctx, self.lib = ctx, ctx.lib
         d, ds = L.shape          # ds = d (white-noise model) or 2d (latent-force model, state [u; eps])
         nB = B.shape[0]
         self._keep = [_f64(L, (d, ds)), _f64(B, (nB, ds)), _f64(E_sqrtm, (d, d)), _f64(R_sqrtm, (nB, nB)),
                       _f64(Gamma, (ds, ds))]
-        desc = FilterDesc(d, int(num_derivatives), nB, *[_dp(a) for a in self._keep], ds)
+        desc = FilterDesc(d, int(num_derivatives), nB, *[_dp(a) for a in self._keep], ds, self.DTYPES[dtype])
+        self.dtype = dtype
         self.ds = ds
         h = _vp()
         ctx.check(self.lib.pnmol_filter_create(ctx.handle, ctypes.byref(desc), ctypes.byref(h)), "pnmol_filter_create")

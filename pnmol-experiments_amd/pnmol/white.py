@@ -41,11 +41,15 @@ class _WhiteNoiseEK1Base(pdefilter.PDEFilter):
         return prior, prior.projection_matrix(0), prior.projection_matrix(1), diffusion_state_sqrtm
 
     _context = None   # set to an `_hip.Context` to run this solver on its own device / stream
+    # Build-side option (the reference is fp64 throughout, src/pnmol/__init__.py:9-11):
+    # "f32" keeps the covariance and its bulk kernels in fp32 (include/pnmol_hip.h, pnmol_filter_desc.dtype;
+    # BASELINE config 5).  Accuracy: DESIGN.md section 11.
+    dtype = "f64"
 
     def _bind(self, pde, gamma):
         ctx = self._context or _hip.Context.default()
         self._device_filter = _hip.Filter(ctx, L=pde.L, B=pde.B, E_sqrtm=pde.E_sqrtm, R_sqrtm=pde.R_sqrtm, Gamma=gamma,
-                                          num_derivatives=self.num_derivatives)
+                                          num_derivatives=self.num_derivatives, dtype=self.dtype)
         self._device_pde = pde
         self._gram = gamma @ gamma.T
         self._error_models = {}
