@@ -1,7 +1,8 @@
 """Problem recipes (reference: src/pnmol/pde/examples.py:13-81, :347-357).
 
-Heat equation and spruce-budworm (Fisher) recipes; the SIR / Lotka-Volterra systems of PDEs are out of scope
-(SURVEY.md section 2, row 11).
+Heat equation (1-d, and a 2-d Dirichlet recipe assembled from the reference's parts), spruce-budworm (Fisher), and the
+Lotka-Volterra / SIR systems of PDEs that figures 3-4 run (examples.py:84-248), with closed-form Jacobians in place of
+`jax.jacfwd`.
 """
 
 import functools

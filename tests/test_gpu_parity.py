@@ -347,3 +347,18 @@ def test_cov_sqrtm_is_the_cholesky_factor(hip_ctx, N, nu, bcond):
         assert first_bad >= n                   # columns behind a lost pivot inherit its arbitrariness
     for c in range(first_bad):
         np.testing.assert_allclose(C[:, c], Co[:, c], rtol=0, atol=1e-3 * np.abs(Co[:, c]).max())
+
+
+def test_stop_at_adjusts_the_step_grid(hip_ctx):
+    """`solve(pde, stop_at=...)` (pdefilter.py:140-160, `_TimeStopper` :238-256): steps are cut at the requested times and
+    the solver hits them exactly; same time grid and numbers as the oracle's driver."""
+    dt = 2.0 ** -6
+    pde, solver, opde, osolver = make_pair(24, 2, dt, 6)
+    stops = [1.5 * dt, 3.25 * dt]
+    sol = solver.solve(pde, stop_at=stops)
+    osol = osolver.solve(opde, stop_at=stops)
+    assert np.array_equal(sol.t, osol.t)
+    assert all(any(abs(t - s) < 1e-15 for t in sol.t) for s in stops)
+    assert sol.info == osol.info
+    omeans, ostds = oracle.read_mean_and_std(osol, osolver.E0)
+    assert_mean_std_parity(sol.mean[:, 0], sol.marginal_std[:, 0], omeans, ostds)
