@@ -45,8 +45,14 @@ class _WhiteNoiseEK1Base(pdefilter.PDEFilter):
     # "f32" keeps the covariance and its bulk kernels in fp32 (include/pnmol_hip.h, pnmol_filter_desc.dtype;
     # BASELINE config 5).  Accuracy: DESIGN.md section 11.
     dtype = "f64"
+    # The fp32 covariance diverges without an error flag for num_derivatives >= 2 (mean errors of 1e10
+    # after 40 steps at N=256): refused unless a study asks for exactly that.
+    allow_unstable_f32 = False
 
     def _bind(self, pde, gamma):
+        if self.dtype == "f32" and self.num_derivatives > 1 and not self.allow_unstable_f32:
+            raise ValueError('dtype="f32" keeps the covariance in single precision, which is only accurate for '
+                             "num_derivatives = 1 (DESIGN.md section 11); use the fp64 path")
         ctx = self._context or _hip.Context.default()
         self._device_filter = _hip.Filter(ctx, L=pde.L, B=pde.B, E_sqrtm=pde.E_sqrtm, R_sqrtm=pde.R_sqrtm, Gamma=gamma,
                                           num_derivatives=self.num_derivatives, dtype=self.dtype)
