@@ -29,6 +29,7 @@
 #include <cstring>
 #include <string>
 #include <utility>
+#include <atomic>
 #include <vector>
 
 #include "pnmol_hip.h"
@@ -908,21 +909,26 @@ __global__ __launch_bounds__(256) void k_panel(double* __restrict__ G, double* _
 constexpr int SWEEP_SPIN_LIMIT = 1 << 18;
 #ifdef PNMOL_SWEEP_STAMP
 __device__ long long pnmol_sweep_stamp[512][8];
-#define SWEEP_STAMP(slot) do { if (tid == 0 && blockIdx.x < 256) pnmol_sweep_stamp[blockIdx.x][slot] = wall_clock64(); } while (0)
-#define SWEEP_STAMP_L(slot) do { if (l == 0 && blockIdx.x < 256) pnmol_sweep_stamp[blockIdx.x][slot] = wall_clock64(); } while (0)
+// (L.stamp_id: the workgroup's index in the layout  0 = chain workgroup, 1 + I = row block I / down-date pair I - RT,
+//  whatever the block mapping of the launch)
+#define SWEEP_STAMP(slot) do { if (tid == 0 && L.stamp_id < 256) pnmol_sweep_stamp[L.stamp_id][slot] = wall_clock64(); } while (0)
+#define SWEEP_STAMP_L(slot) do { if (l == 0 && L.stamp_id < 256) pnmol_sweep_stamp[L.stamp_id][slot] = wall_clock64(); } while (0)
 // per-step trace of ONE workgroup (block PNMOL_SWEEP_TRACE_WG): rows 256 + j
 #ifndef PNMOL_SWEEP_TRACE_WG
 #define PNMOL_SWEEP_TRACE_WG 16
 #endif
-#define SWEEP_TRACE(j, slot) do { if (tid == 0 && blockIdx.x == PNMOL_SWEEP_TRACE_WG) pnmol_sweep_stamp[256 + (j)][slot] = wall_clock64(); } while (0)
+#define SWEEP_TRACE(j, slot) do { if (tid == 0 && L.stamp_id == PNMOL_SWEEP_TRACE_WG) pnmol_sweep_stamp[256 + (j)][slot] = wall_clock64(); } while (0)
 // the publishing wave (w == 2) of the traced workgroup: rows 320 + j
-#define SWEEP_TRACE_W2(j, slot) do { if (w == 2 && l == 0 && blockIdx.x == PNMOL_SWEEP_TRACE_WG) pnmol_sweep_stamp[320 + (j)][slot] = wall_clock64(); } while (0)
+#define SWEEP_TRACE_W2(j, slot) do { if (w == 2 && l == 0 && L.stamp_id == PNMOL_SWEEP_TRACE_WG) pnmol_sweep_stamp[320 + (j)][slot] = wall_clock64(); } while (0)
 // the chain workgroup of k_sweep_rl (block 0): rows 384 + J
 // (stamped builds only) wait for this wave's outstanding loads, then stamp: separates load latency from what follows
 #define SWEEP_TRACE_VM(j, slot) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SWEEP_TRACE(j, slot); } while (0)
 #define CHAIN_TRACE(J, slot) do { if (tid == 0) pnmol_sweep_stamp[384 + (J)][slot] = wall_clock64(); } while (0)
 #define CHAIN_TRACE_W(J, slot, wave) do { if (l == 0 && w == (wave)) pnmol_sweep_stamp[384 + (J)][slot] = wall_clock64(); } while (0)
+// shader-clock counter (s_memtime) next to the constant 100 MHz one: their ratio is the clock the chain workgroup's CU ran at
+#define CHAIN_TRACE_CLK(J, slot) do { if (tid == 0) pnmol_sweep_stamp[384 + (J)][slot] = clock64(); } while (0)
 #else
+#define CHAIN_TRACE_CLK(J, slot) do {} while (0)
 #define SWEEP_TRACE_VM(j, slot) do {} while (0)
 #define SWEEP_TRACE_W2(j, slot) do {} while (0)
 #define CHAIN_TRACE(J, slot) do {} while (0)
@@ -942,6 +948,7 @@ struct SweepLds {
     int dead, pub;
     int pubcnt;              // k_sweep_rl: waves whose stores of the tiles so far have drained (4 per step)
     int rdiag, rnew, rcol, rzb;  // k_sweep_rl: what wave 0 has seen in global memory (relay_wait_ge)
+    int stamp_id;            // (timeline builds, -DPNMOL_SWEEP_STAMP) index of this workgroup's stamps
     Diag4Lds d4;             // the diagonal block's four-wave factorisation (flags zeroed at kernel start)
 };
 // the chain workgroup of k_sweep_rl (it factorises every diagonal block)
@@ -978,19 +985,46 @@ typedef int v4i_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wt_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7ffffffc, 0x00020000);
 }
+template <int AUX = 16 /* sc1: write-through */>
 __device__ __forceinline__ void wt_st2(__amdgpu_buffer_rsrc_t r, unsigned byte_off, double a, double b) {
     const v4i_t v = {__double2loint(a), __double2hiint(a), __double2loint(b), __double2hiint(b)};
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, 16 /* sc1 */);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, AUX);
 }
 // rows [row0, row0 + 4 NE) of a 32x32 tile from LDS (leading dimension TLD) to global memory (tile origin at byte offset
-// `org` of the buffer, leading dimension ld), by one wave: NE full 1-KB store instructions
-template <int NE>
+// `org` of the buffer, leading dimension ld), by one wave: NE full 1-KB store instructions.  AUX = 0: plain stores (the
+// data stops in this XCD's L2: readers on the same XCD only)
+template <int NE, int AUX = 16>
 __device__ __forceinline__ void wt_rows_from_lds(__amdgpu_buffer_rsrc_t r, unsigned org, long ld, const double* s, int row0, int l) {
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
         const int idx = l + 64 * e, row = row0 + (idx >> 4), c2 = 2 * (idx & 15);
-        wt_st2(r, org + (unsigned)((row * ld + c2) * 8), s[row * TLD + c2], s[row * TLD + c2 + 1]);
+        wt_st2<AUX>(r, org + (unsigned)((row * ld + c2) * 8), s[row * TLD + c2], s[row * TLD + c2 + 1]);
     }
+}
+// A whole tile held by one wave (8 x 2 doubles per lane, taken from LDS once): stored twice by the chain workgroup, first
+// into its XCD's L2, later written through for everybody else.
+struct TileRegs {
+    double v[16];
+};
+__device__ __forceinline__ void tile_regs_from_lds(TileRegs& t, const double* s, int l) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int idx = l + 64 * e, row = idx >> 4, c2 = 2 * (idx & 15);
+        t.v[2 * e] = s[row * TLD + c2];
+        t.v[2 * e + 1] = s[row * TLD + c2 + 1];
+    }
+}
+template <int AUX>
+__device__ __forceinline__ void tile_regs_store(const TileRegs& t, __amdgpu_buffer_rsrc_t r, unsigned org, long ld, int l) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int idx = l + 64 * e, row = idx >> 4, c2 = 2 * (idx & 15);
+        wt_st2<AUX>(r, org + (unsigned)((row * ld + c2) * 8), t.v[2 * e], t.v[2 * e + 1]);
+    }
+}
+// a flag word for pollers on the SAME XCD: plain store, it stops in the L2 the pollers' sc1 loads are served from
+__device__ __forceinline__ void l2_flag_st(__amdgpu_buffer_rsrc_t rflags, int word, int v) {
+    __builtin_amdgcn_raw_buffer_store_b32(v, rflags, (unsigned)word * 4u, 0, 0);
 }
 // a 32x32 tile (row-major, leading dimension NB, at byte offset `org`) that ANOTHER workgroup has published, into LDS
 // (leading dimension TLD), by one wave
@@ -1473,6 +1507,9 @@ __global__ __launch_bounds__(256) void k_sweep(const double* __restrict__ G, dou
     // Block -> row block.  The r^T block (row block zb of the tall matrix) is dealt right behind the rows of S, before the
     // rows of W and of Ls^-T, which wait for it at their end (vector ops): dependencies keep pointing to lower blocks.
     int I = blockIdx.x;
+#ifdef PNMOL_SWEEP_STAMP
+    if (tid == 0) L.stamp_id = blockIdx.x;
+#endif
     {
         const int zb = RT - CB - 1;
         if (I >= CB && I <= zb) I = (I == CB) ? zb : I - 1;
@@ -1776,7 +1813,7 @@ __global__ __launch_bounds__(256) void k_sweep(const double* __restrict__ G, dou
 //   fcol[RL_REP][CBp]   number of chain rows that have published their own tile p  (atomic adds)
 constexpr int RL_REP = 8;
 struct RlFlags {
-    int frow, fabort, ffeed, fdiag, fnew, fcol, CBp, total;
+    int frow, fabort, fxcc, ffeed, fdiag, fnew, fcol, fdiagL, fnewL, CBp, total;
 };
 __host__ __device__ inline RlFlags rl_flags(int RT, int CB) {
     const int RTp = (RT + 31) / 32 * 32, CBp = (CB + 31) / 32 * 32;
@@ -1784,13 +1821,18 @@ __host__ __device__ inline RlFlags rl_flags(int RT, int CB) {
     f.CBp = CBp;
     f.frow = 0;
     f.fabort = RTp;
+    f.fxcc = RTp + 16;  // 1 + XCC id of the chain workgroup (half a line away from the abort word: read once per workgroup)
     f.ffeed = RTp + 32;
     f.fdiag = f.ffeed + CBp;
     f.fnew = f.fdiag + RL_REP * CBp;
     f.fcol = f.fnew + RL_REP * CBp;
-    f.total = f.fcol + RL_REP * CBp;
+    f.fdiagL = f.fcol + RL_REP * CBp;  // copies of fdiag / fnew that live in the chain workgroup's XCD (see XL below)
+    f.fnewL = f.fdiagL + CBp;
+    f.total = f.fnewL + CBp;
     return f;
 }
+// The XCC (XCD) this wave runs on.
+__device__ __forceinline__ int xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15; }
 struct WaveWait {
     bool dead;
 };
@@ -1821,18 +1863,155 @@ __device__ __forceinline__ void relay_wait_ge(const int* p, int need, int* relay
     asm volatile("" ::: "memory");
 }
 
+// Progress polls.  A row block that lags behind the chain workgroup would pay a memory round trip (0.3-1 us) per wait for
+// flags that were set long ago.  One poll reads ALL the words of a flag array (lane k reads p[k]) and yields the length of
+// the leading run of finished entries (entry k is finished when p[k] >= need(k)); wave 0 remembers it (`known`) and only
+// polls again when a step needs more than it knows.  The relay word carries `known` to the other waves.
+template <class Need>
+__device__ __forceinline__ void relay_progress(const int* p, int cnt, Need need, int want, int& known, int* relay, int* fabort,
+                                               WaveWait& ww, int w, int l) {
+    if (w == 0) {
+        if (known < want) {
+            for (int spins = 0; !ww.dead; ++spins) {
+                const int v = l < cnt ? flag_ld(p + l) : 0;
+                const unsigned long long ok = __ballot(l < cnt && v >= need(l));
+                known = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(~ok));
+                if (known >= want) break;
+                if (spins > SWEEP_SPIN_LIMIT || ((spins & 63) == 63 && flag_ld(fabort))) {
+                    ww.dead = true;
+                    flag_st(fabort, 1);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __hip_atomic_store(relay, ww.dead ? (1 << 30) : known, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    } else {
+        int v;
+        while ((v = __hip_atomic_load(relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < want) __builtin_amdgcn_s_sleep(1);
+        if (v == (1 << 30)) ww.dead = true;
+    }
+    asm volatile("" ::: "memory");
+}
+// The same for "every word of p[0 .. cnt-1] is >= want": wave 0 remembers the minimum it has seen (valid for later, shorter
+// ranges that end at the same word and for smaller `want`).
+__device__ __forceinline__ void relay_progress_min(const int* p, int cnt, int want, int& known, int* relay, int* fabort,
+                                                   WaveWait& ww, int w, int l) {
+    if (w == 0) {
+        if (known < want) {
+            for (int spins = 0; !ww.dead; ++spins) {
+                int v = l < cnt ? flag_ld(p + l) : (1 << 29);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+                known = __builtin_amdgcn_readfirstlane(v);
+                if (known >= want) break;
+                if (spins > SWEEP_SPIN_LIMIT || ((spins & 63) == 63 && flag_ld(fabort))) {
+                    ww.dead = true;
+                    flag_st(fabort, 1);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __hip_atomic_store(relay, ww.dead ? (1 << 30) : known, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    } else {
+        int v;
+        while ((v = __hip_atomic_load(relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < want) __builtin_amdgcn_s_sleep(1);
+        if (v == (1 << 30)) ww.dead = true;
+    }
+    asm volatile("" ::: "memory");
+}
+// The same for a RANGE of words: p[0 .. cnt-1] >= need, cnt <= 64 (one load instruction per poll: lane k reads p[k]).
+__device__ __forceinline__ void relay_wait_range_ge(const int* p, int cnt, int need, int* relay, int tag, int* fabort,
+                                                    WaveWait& ww, int w, int l) {
+    if (w == 0) {
+        if (!ww.dead) {
+            for (int spins = 0;; ++spins) {
+                const int v = l < cnt ? flag_ld(p + l) : need;
+                if (__all(v >= need)) break;
+                if (spins > SWEEP_SPIN_LIMIT || ((spins & 63) == 63 && flag_ld(fabort))) {
+                    ww.dead = true;
+                    flag_st(fabort, 1);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __hip_atomic_store(relay, ww.dead ? (1 << 30) : tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+        int v;
+        while ((v = __hip_atomic_load(relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < tag) __builtin_amdgcn_s_sleep(1);
+        if (v == (1 << 30)) ww.dead = true;
+    }
+    asm volatile("" ::: "memory");
+}
+
+// ---- bulk operand ring of k_sweep_rl ------------------------------------------------------------------------------
+// The rank-32 update of a row block reads one 32x32 tile of L per tile it updates; as fragment loads to registers with one
+// tile of look-ahead (all the register file allows) a tile took 0.45 us against 0.21 us of MFMA: one miss latency each.
+// Each wave now streams ITS half tiles (16 rows x 256 B) through a private LDS ring filled by LDS-DMA
+// (global_load_lds_dwordx4: no registers, RING tiles ahead, no workgroup barrier), and reads its B fragments with
+// ds_read_b128.  An LDS-DMA instruction writes 64 x 16 B contiguously, so the image is row-major without padding and the
+// bank conflicts of 16 lanes reading 16 rows at one column are avoided by XOR-swizzling the 16-byte column index with the
+// row on the SOURCE address: slot (row, g ^ row) holds columns 2g, 2g+1 of the row.
+constexpr int RING = 4;
+// one 16-byte LDS-DMA per lane: LDS[lds_dst + 16 lane] = *gsrc   (M0 is written and restored in the same statement)
+__device__ __forceinline__ void lds_dma16(const double* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// half tile (rows wc*16 .. +15 of the tile at `tile`, leading dimension ld) -> ring slot at LDS byte address `slot`
+__device__ __forceinline__ void ring_fill(const double* tile, const int (&off)[4], unsigned slot) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) lds_dma16(tile + off[c], slot + 1024u * c);
+}
+// at most `tiles_behind` later half tiles (4 DMAs each) may still be in flight
+__device__ __forceinline__ void ring_wait(int tiles_behind) {
+    switch (tiles_behind) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    }
+}
+// B fragment of lane (fr, fk) from a ring slot: row fr, columns 8 fk .. 8 fk + 7
+__device__ __forceinline__ void ring_frag(Frag8& f, const double* slot, int fr, int fk) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const double2 t = *reinterpret_cast<const double2*>(slot + (fr * 16 + ((4 * fk + e) ^ fr)) * 2);
+        f.v[2 * e] = t.x;
+        f.v[2 * e + 1] = t.y;
+    }
+}
+
 // The chain workgroup (block 0 of k_sweep_rl): factorises ALL diagonal blocks one after the other, so no hand-over between
 // workgroups sits on the critical path.  Block J needs  D_J = D'_J - X X^T,  X = X_{J,J-1} = S_{J,J-1} L_{J-1,J-1}^-T:
 // row block J feeds S_{J,J-1} and -D'_J (everything that does not depend on block J-1's factor: ready about one
 // factorisation earlier) through `feed`; wave 0, idle during the second half of factorisation J-1, brings them into LDS;
 // L_{J-1,J-1}^-1 goes from wave 1's registers through LDS; X is published as tile (J, J-1) of F by wave 2, which also
 // writes the previous L_JJ and checks its pivots while the others go on.
+//
+// XL ("XCD-local"): the launch has placed the chain workgroup and the row blocks of S -- everybody on the critical loop
+// L^-1, X -> row J+1 -> feed -> next factorisation -- on blockIdx = 0 mod 8, i.e. on ONE XCD (round-robin dispatch; each row
+// block checks it against the XCC id published here and falls back to the write-through flags if not).  A hand-over inside
+// an XCD needs no write-through: plain stores stop in the shared L2, where the readers' L1-bypassing loads find them
+// (tools/hop_load_bench.hip: 0.7-1.1 us per hop against 1.2-1.6 us, and the write-through latency grows with the fabric
+// traffic of the down-date workgroups).  L^-1 and X are therefore stored twice: into the L2 first (flags fdiagL / fnewL),
+// written through afterwards for the readers on the other XCDs (W rows, identity rows, down-date: fdiag / fnew as before).
+template <bool XL>
 __device__ __forceinline__ void sweep_chain_role(ChainLds& C, const double* __restrict__ G, double* F, double* Linv, int ld,
-                                                 int CB, int* fdiag_all, int* fnew_all, int CBp, int* ffeed, int* fabort, int* info,
+                                                 int CB, int* flags, const RlFlags& fl, int* info,
                                                  double* feed, int lenient, int tid, int l, int w) {
+    int* fdiag_all = flags + fl.fdiag;
+    int* fnew_all = flags + fl.fnew;
+    const int CBp = fl.CBp;
+    int* ffeed = flags + fl.ffeed;
+    int* fabort = flags + fl.fabort;
     const int wr = w >> 1, wc = w & 1, fr = l & 15, fk = l >> 4;
     const int offC = (wr * 16 + fk) * TLD + wc * 16 + fr;
-    const __amdgpu_buffer_rsrc_t rF = wt_rsrc(F), rlinv = wt_rsrc(Linv), rfeed = wt_rsrc(feed);
+    const __amdgpu_buffer_rsrc_t rF = wt_rsrc(F), rlinv = wt_rsrc(Linv), rfeed = wt_rsrc(feed), rflags = wt_rsrc(flags);
+    if (XL && tid == 0) flag_st(flags + fl.fxcc, 1 + xcc_id());
     WaveWait ww{false};
     double smax = 0.0;
     for (int e = tid; e < ld; e += 256) smax = fmax(smax, fabs(G[(long)e * ld + e]));
@@ -1855,6 +2034,7 @@ __device__ __forceinline__ void sweep_chain_role(ChainLds& C, const double* __re
     for (int J = 0; J < CB; ++J) {
         Diag4Lds* dl = &C.d4[J & 1];
         CHAIN_TRACE(J, 0);
+        CHAIN_TRACE_CLK(J, 4);
         if (w == 2 && J > 0)  // L_{J-1,J-1} and its pivots, off the critical path
             diag4_output(&C.d4[(J - 1) & 1], l, F + ((long)(J - 1) * NB) * ld + (long)(J - 1) * NB, ld, info, (J - 1) * NB,
                          C.sd[(J - 1) & 1], smax, pivtol);
@@ -1870,6 +2050,7 @@ __device__ __forceinline__ void sweep_chain_role(ChainLds& C, const double* __re
                 wt_rows_from_lds<8>(rlinv, (unsigned)(J * NB * NB * 8), NB, C.sLinv, 0, l);
                 drain_vmem();
                 if (l < RL_REP) flag_st(fdiag_all + l * CBp + J, 1);
+                if (XL && l == 0) l2_flag_st(rflags, fl.fdiagL + J, 1);
             }
             break;
         }
@@ -1884,7 +2065,15 @@ __device__ __forceinline__ void sweep_chain_role(ChainLds& C, const double* __re
         if (tid < 16) C.d4[(J + 1) & 1].flagA[tid] = 0;
         // w2 sends L_JJ^-1 on its way NOW (everybody else's TRSM of step J waits for it); the stores drain behind this
         // block's TRSM
-        if (w == 2) wt_rows_from_lds<8>(rlinv, (unsigned)(J * NB * NB * 8), NB, C.sLinv, 0, l);
+        TileRegs tl;
+        if (w == 2) {
+            if constexpr (XL) {
+                tile_regs_from_lds(tl, C.sLinv, l);
+                tile_regs_store<0>(tl, rlinv, (unsigned)(J * NB * NB * 8), NB, l);
+            } else {
+                wt_rows_from_lds<8>(rlinv, (unsigned)(J * NB * NB * 8), NB, C.sLinv, 0, l);
+            }
+        }
         // X = S L^-T  (A: rows of S from LDS, B: rows of L^-1 from LDS)
         d4 x = {0, 0, 0, 0};
 #pragma unroll
@@ -1899,16 +2088,35 @@ __device__ __forceinline__ void sweep_chain_role(ChainLds& C, const double* __re
         CHAIN_TRACE(J, 3);
         if (w == 2) {
             drain_vmem();
-            if (l < RL_REP) flag_st(fdiag_all + l * CBp + J, 1);  // all copies, one store instruction
+            if constexpr (XL) {
+                if (l == 0) l2_flag_st(rflags, fl.fdiagL + J, 1);
+            } else {
+                if (l < RL_REP) flag_st(fdiag_all + l * CBp + J, 1);  // all copies, one store instruction
+            }
         }
 #pragma unroll
         for (int s = 0; s < 8; ++s)
             accD = __builtin_amdgcn_mfma_f64_16x16x4f64(C.sX[(wr * 16 + fr) * TLD + 8 * fk + s],
                                                         C.sX[(wc * 16 + fr) * TLD + 8 * fk + s], accD, 0, 0, 0);
         if (w == 2) {  // tile (J+1, J) of F: the other row blocks' "newest" operand of step J+1
-            wt_rows_from_lds<8>(rF, (unsigned)((((long)(J + 1) * NB) * ld + (long)J * NB) * 8), ld, C.sX, 0, l);
-            drain_vmem();
-            if (l < RL_REP) flag_st(fnew_all + l * CBp + J, 1);
+            const unsigned orgX = (unsigned)((((long)(J + 1) * NB) * ld + (long)J * NB) * 8);
+            if constexpr (XL) {
+                TileRegs tx;
+                tile_regs_from_lds(tx, C.sX, l);
+                tile_regs_store<0>(tx, rF, orgX, ld, l);
+                drain_vmem();
+                if (l == 0) l2_flag_st(rflags, fl.fnewL + J, 1);
+                // ... and now both tiles once more, written through, for the row blocks on the other XCDs
+                tile_regs_store<16>(tl, rlinv, (unsigned)(J * NB * NB * 8), NB, l);
+                tile_regs_store<16>(tx, rF, orgX, ld, l);
+                drain_vmem();
+                if (l < RL_REP) flag_st(fdiag_all + l * CBp + J, 1);
+                if (l < RL_REP) flag_st(fnew_all + l * CBp + J, 1);
+            } else {
+                wt_rows_from_lds<8>(rF, orgX, ld, C.sX, 0, l);
+                drain_vmem();
+                if (l < RL_REP) flag_st(fnew_all + l * CBp + J, 1);
+            }
         }
     }
     if (w == 2)
@@ -1917,15 +2125,16 @@ __device__ __forceinline__ void sweep_chain_role(ChainLds& C, const double* __re
     if (l == 0 && ww.dead) atomicMin(info, -2);
 }
 
-template <int N, bool FUSED, int MAXT>
+template <int N, bool FUSED, int MAXT, bool XL>
 __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, double* F, double* Linv, int ld, int CB,
                                                   int RT, int* flags, int* info_base, const int* __restrict__ ctr,
-                                                  DowndateArgs dd, double* feed, int lenient) {
+                                                  DowndateArgs dd, double* feed, int lenient, int home) {
     __shared__ __attribute__((aligned(16))) union {
         SweepLds L;
         ChainLds C;
     } lds;
     SweepLds& L = lds.L;
+    __shared__ __attribute__((aligned(16))) double bulk_ring[4][RING][16 * NB];  // per wave: RING half tiles (4 KB each)
     const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = w >> 1, wc = w & 1, fr = l & 15, fk = l >> 4;
     const RlFlags fl = rl_flags(RT, CB);
@@ -1936,12 +2145,39 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
     const int* fnew = flags + fl.fnew + (blockIdx.x % RL_REP) * fl.CBp;
     const int* fcol = flags + fl.fcol + (blockIdx.x % RL_REP) * fl.CBp;
     int* info = info_base + (*ctr - 1);
-    if (blockIdx.x == 0) {
-        sweep_chain_role(lds.C, G, F, Linv, ld, CB, flags + fl.fdiag, flags + fl.fnew, fl.CBp, ffeed, fabort, info, feed, lenient,
-                         tid, l, w);
+    // XL: the launch starts `home` (0 .. 7) empty blocks early, so that block 0 of the layout below -- the chain workgroup --
+    // and the row blocks of S land on XCD `home`: sweeps of different filters that share the device get different XCDs
+    // (with all of them on XCD 0, eight problems in flight fought over its 32 CUs: 7.0 k steps/s against 8.7 k)
+    const int bx = XL ? (int)blockIdx.x - home : (int)blockIdx.x;
+    if (bx < 0) return;
+    if (bx == 0) {
+        sweep_chain_role<XL>(lds.C, G, F, Linv, ld, CB, flags, fl, info, feed, lenient, tid, l, w);
         return;
     }
-    int I = blockIdx.x - 1;
+    // !XL: block 1 + I is row block I.  XL: blocks 8 s, s = 1 .. CB-1, are the row blocks of S (I = s: the chain workgroup's
+    // XCD) and the blocks between them are empty -- every dependency must point to a LOWER block index: workgroups are
+    // dispatched in index order, and when several sweeps share the device a workgroup that spins on a block which has no
+    // CU yet would never let it have one.  The remaining row blocks and the down-date pairs follow behind block 8 (CB-1).
+    int I;
+    if constexpr (XL) {
+        const int b = bx, nslot = 8 * (CB - 1) + 1;
+        if (b < nslot) {
+            if (b % 8 != 0) return;
+            I = b / 8;
+        } else {
+            // ... on the seven other XCDs: the chain workgroup's XCD (32 CUs) keeps its CUs for the CB workgroups above --
+            // with every eighth of the remaining workgroups on it as well, some of them found no CU for most of the sweep
+            if (b % 8 == 0) return;
+            const int q = b - nslot;  // (nslot = 1 mod 8: block nslot + q is empty when (q + 1) % 8 == 0)
+            I = CB + q - (q + 1) / 8;
+        }
+    } else {
+        I = bx - 1;
+    }
+#ifdef PNMOL_SWEEP_STAMP
+    if (tid == 0) L.stamp_id = 1 + I;  // (visible to everybody behind the workgroup's first barrier; only thread 0 and
+                                       //  lane-0 threads behind later barriers stamp)
+#endif
     {
         const int zb = RT - CB - 1;  // the r^T block is dealt right behind the rows of S (see k_sweep)
         if (I >= CB && I <= zb) I = (I == CB) ? zb : I - 1;
@@ -1961,7 +2197,8 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
     }
     if (chain && I == 0) return;  // (block (0,0) is the chain workgroup's own)
     if (tid == 0) {
-        L.dead = 0, L.pubcnt = 0, L.rdiag = -1, L.rnew = -1, L.rcol = -1, L.rzb = 0;
+        L.dead = 0, L.pubcnt = 0, L.rdiag = 0, L.rnew = 0, L.rcol = 0, L.rzb = 0;
+        L.seen[0] = 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // one invalidate per workgroup (see k_sweep)
     }
     __syncthreads();
@@ -1990,7 +2227,32 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
         }
     }
     WaveWait ww{false};
-    const __amdgpu_buffer_rsrc_t rF = wt_rsrc(F), rfeed = wt_rsrc(feed);
+    int known_diag = 0, known_new = 0, known_col = 0;  // wave 0: progress seen so far (relay_progress)
+    const __amdgpu_buffer_rsrc_t rF = wt_rsrc(F), rfeed = wt_rsrc(feed), rflags = wt_rsrc(flags);
+    // this wave's bulk operand ring and its lanes' source offsets (element units) inside a tile, per DMA instruction
+    const double* ringw = &bulk_ring[w][0][0];
+    const unsigned ring0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)ringw);
+    int roff[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int row = 4 * c + (l >> 4);
+        roff[c] = (wc * 16 + row) * ld + 2 * ((l & 15) ^ row);
+    }
+    // XL: a row block of S that does share the chain workgroup's XCD takes L^-1 and the newest tile from the L2 (flags
+    // fdiagL / fnewL) and feeds through it
+    bool local = false;
+    if constexpr (XL) {
+        if (chain) {
+            if (tid == 0) {
+                int v = 0;
+                for (int spins = 0; spins < 4096 && (v = flag_ld(flags + fl.fxcc)) == 0; ++spins) __builtin_amdgcn_s_sleep(1);
+                L.seen[0] = (v == 1 + xcc_id());
+            }
+            __syncthreads();
+            local = L.seen[0] != 0;
+            if (local) fdiag = flags + fl.fdiagL, fnew = flags + fl.fnewL;
+        }
+    }
     Frag8 ax;  // rows wr*16 + fr of X_{j-1}, columns 8 fk .. 8 fk + 7 (A operand of both updates of step j)
     // Tile t of this row block is published once the stores of all four waves have completed; the last wave to say so
     // sets the flag(s).  Called right behind the first wait for a LOAD issued after those stores (memory operations of a
@@ -2014,7 +2276,8 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
             const double* sXp = ((j - 1) & 1) ? L.sP[0] : L.sX;
 #pragma unroll
             for (int s = 0; s < 8; ++s) ax.v[s] = sXp[(wr * 16 + fr) * TLD + 8 * fk + s];
-            relay_wait_ge(fnew + j - 1, 1, &L.rnew, j, fabort, ww, w);  // tile (j, j-1), from the chain workgroup
+            // tile (j, j-1), from the chain workgroup
+            relay_progress(fnew, CB - 1, [](int) { return 1; }, j, known_new, &L.rnew, fabort, ww, w, l);
             SWEEP_TRACE(j, 1);
             Frag8 b0;
             frag_ld(b0, F + ((long)j * NB + wc * 16 + fr) * ld + (long)(j - 1) * NB + 8 * fk);
@@ -2030,13 +2293,21 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
                 L.sS[1][offC + 4 * r * TLD] = accD[r];
             }
             __syncthreads();
-            wt_rows_from_lds<2>(rfeed, (unsigned)((2 * I) * NB * NB * 8), NB, L.sS[0], 8 * w, l);
-            wt_rows_from_lds<2>(rfeed, (unsigned)((2 * I + 1) * NB * NB * 8), NB, L.sS[1], 8 * w, l);
+            if (XL && local) {
+                wt_rows_from_lds<2, 0>(rfeed, (unsigned)((2 * I) * NB * NB * 8), NB, L.sS[0], 8 * w, l);
+                wt_rows_from_lds<2, 0>(rfeed, (unsigned)((2 * I + 1) * NB * NB * 8), NB, L.sS[1], 8 * w, l);
+            } else {
+                wt_rows_from_lds<2>(rfeed, (unsigned)((2 * I) * NB * NB * 8), NB, L.sS[0], 8 * w, l);
+                wt_rows_from_lds<2>(rfeed, (unsigned)((2 * I + 1) * NB * NB * 8), NB, L.sS[1], 8 * w, l);
+            }
             SWEEP_TRACE(j, 2);
             drain_vmem();
             SWEEP_TRACE(j, 3);
             __syncthreads();
-            if (tid == 0) flag_st(ffeed + I, 1);
+            if (tid == 0) {
+                if (XL && local) l2_flag_st(rflags, fl.ffeed + I, 1);
+                else flag_st(ffeed + I, 1);
+            }
             SWEEP_TRACE(j, 4);
             SWEEP_STAMP(1);
             break;
@@ -2046,20 +2317,58 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
         for (int r = 0; r < 4; ++r) sS[offC + 4 * r * TLD] = -acc[r];
         __syncthreads();  // S_j complete
         SWEEP_TRACE(j, 2);
-        // While L_jj^-1 is on its way: the first operand of the update (3) -- tile (j+1, j-1) was published a whole
-        // step ago; its load latency would otherwise sit between X_j and the next tile's S for the rows that feed the
-        // chain workgroup
         const int tl = ntiles - 1;
         const bool bulk = j >= 1 && j + 1 < ntiles;
-        const double* Lp = F + ((long)wc * 16 + fr) * ld + (long)(j - 1) * NB + 8 * fk;  // + t * NB * ld: tile (t, j-1)
-        Frag8 bq[2];
+        // (3) panel j-1 on the tiles j+1 .. ntiles-1; the slots move down by one.  Done BEFORE the wait for L_jj^-1: its
+        // operands, tiles (t, j-1), were published a whole step ago, and a row block of S near the diagonal -- the next ones
+        // to feed the chain workgroup -- would otherwise do this work between L_jj^-1 and its feed.
         if (bulk) {
-            // tiles (t, j-1), t = j+1 .. CB-1, are their rows' own publications: CB-1-j of them
-            relay_wait_ge(fcol + j - 1, CB - 1 - j, &L.rcol, j, fabort, ww, w);
-            frag_ld(bq[1], Lp + (long)(j + 1) * NB * ld);
+            // A row block of S reads tiles (t, j-1) of the rows t = j+1 .. I-1 only, all of them ahead of it: it waits for
+            // exactly those (frow[t] >= j); the others wait for the panel's counter (CB-1-j publications)
+            if (chain) relay_progress_min(frow + j + 1, I - 1 - j, j, known_col, &L.rcol, fabort, ww, w, l);
+            else relay_progress(fcol, CB - 1, [CB](int k) { return CB - 2 - k; }, j, known_col, &L.rcol, fabort, ww, w, l);
+            const int cnt = tl - j;  // tiles j+1 .. tl
+            const double* Lt = F + (long)(j - 1) * NB + (long)(j + 1) * NB * ld;  // tile (j+1, j-1); + k * NB * ld
+#pragma unroll
+            for (int r = 0; r < RING; ++r)
+                if (r < cnt) ring_fill(Lt + (long)r * NB * ld, roff, ring0 + 4096u * r);
+            // The fragments of tile k+1 are read from the ring right behind the FIRST of the eight dependent MFMAs of tile k
+            // (pinned there: the compiler's in-order lgkmcnt bookkeeping would otherwise make tile k's MFMAs wait for them) and
+            // land while the other seven run: with one wave per SIMD nothing else hides the ds_read latency.
+            Frag8 b[2];
+            ring_wait(cnt - 1 < RING - 1 ? cnt - 1 : RING - 1);
+            ring_frag(b[0], ringw, fr, fk);
+#pragma unroll
+            for (int u = 1; u < MAXT; ++u) {
+                if (j + u <= tl) {
+                    const int k = u - 1;
+                    // b[k & 1] is here: slot k % RING is free again.  (The builtin, not an asm statement: the compiler then
+                    // knows that nothing older is pending and does not make this tile's MFMAs wait for the next reads.)
+                    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+                    asm volatile("" ::: "memory");
+                    if (k + RING < cnt) ring_fill(Lt + (long)(k + RING) * NB * ld, roff, ring0 + 4096u * (k % RING));
+                    d4 a = __builtin_amdgcn_mfma_f64_16x16x4f64(ax.v[0], b[k & 1].v[0], n[u], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (k + 1 < cnt) {
+                        const int behind = cnt - 2 - k;  // tiles issued after tile k+1 (capped by the ring)
+                        ring_wait(behind < RING - 1 ? behind : RING - 1);
+                        ring_frag(b[(k + 1) & 1], ringw + 512 * ((k + 1) % RING), fr, fk);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int s = 1; s < 8; ++s)
+                        a = __builtin_amdgcn_mfma_f64_16x16x4f64(ax.v[s], b[k & 1].v[s], a, 0, 0, 0);
+                    n[u - 1] = a;
+                }
+            }
+        } else if (j == 0) {
+#pragma unroll
+            for (int u = 1; u < MAXT; ++u)
+                if (u < ntiles) n[u - 1] = n[u];
         }
+        SWEEP_TRACE(j, 4);
         // (2) X_j = S_j L_jj^-T
-        relay_wait_ge(fdiag + j, 1, &L.rdiag, j, fabort, ww, w);
+        relay_progress(fdiag, CB, [](int) { return 1; }, j + 1, known_diag, &L.rdiag, fabort, ww, w, l);
         SWEEP_TRACE(j, 5);
         Frag8 bl;
         frag_ld(bl, Linv + (long)j * NB * NB + (wc * 16 + fr) * NB + 8 * fk);
@@ -2084,25 +2393,6 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
                                                             sXj[(wc * 16 + fr) * TLD + 8 * fk + s], accD, 0, 0, 0);
         }
         SWEEP_TRACE(j, 3);
-        // (3) panel j-1 on the tiles j+1 .. ntiles-1; the slots move down by one
-        if (bulk) {
-#pragma unroll
-            for (int u = 1; u < MAXT; ++u) {
-                if (j + u <= tl) {
-                    const int tn = (j + u + 1 <= tl) ? j + u + 1 : tl;  // (clamped: the load is unconditional)
-                    frag_ld(bq[(u + 1) & 1], Lp + (long)tn * NB * ld);
-                    d4 a = n[u];
-#pragma unroll
-                    for (int s = 0; s < 8; ++s)
-                        a = __builtin_amdgcn_mfma_f64_16x16x4f64(ax.v[s], bq[u & 1].v[s], a, 0, 0, 0);
-                    n[u - 1] = a;
-                }
-            }
-        } else if (j == 0) {
-#pragma unroll
-            for (int u = 1; u < MAXT; ++u)
-                if (u < ntiles) n[u - 1] = n[u];
-        }
         SWEEP_TRACE(j, 4);
         SWEEP_TRACE(j, 6);
     }
@@ -2429,6 +2719,8 @@ struct pnmol_filter {
     int sweep_mode = 2;    // PNMOL_HIP_SWEEP: 2 = k_sweep with the covariance down-date riding along in the same launch,
                            // 1 = k_sweep, then k_downdate; 0 = k_diag0 + one k_panel launch per panel, then k_downdate
     int ds = 0;  // spatial components of the state (= d, or 2d for the latent-force model [u; eps])
+    bool counted = false;  // this filter is in live_filters
+    int xcd_home = -1;  // k_sweep_rl: >= 0: XCD-local layout (XL), chain workgroup and S row blocks on this XCD; -1: spread layout
     int p32 = 0;        // pnmol_filter_desc.dtype = 1: covariances (state, predicted, Q) are stored and down-dated in fp32
     size_t psz = 8;     // bytes per covariance element
     long Dp = 0;
@@ -2501,15 +2793,36 @@ inline bool sweep_rl_enabled() {
     }();
     return on != 0;
 }
+// PNMOL_HIP_SWEEP_XL: 1 / 0 force the XCD-local layout on / off for every filter; unset: the first live filter of the process
+// gets it.  It trades throughput of SEVERAL sweeps in flight (their chain workgroups and S row blocks are pinned to one XCD
+// each and everything behind them in dispatch order waits for a CU there: 7.3 k steps/s with eight problems in flight
+// against 8.7 k with the spread layout) for latency of one (159 against 170 us per step).
+inline int sweep_xl_mode() {
+    static const int mode = [] {
+        const char* e = std::getenv("PNMOL_HIP_SWEEP_XL");
+        return e ? (std::atoi(e) != 0 ? 1 : 0) : -1;
+    }();
+    return mode;
+}
+std::atomic<int> live_filters{0};
 template <int N, bool FUSED>
 void launch_sweep(unsigned grid, hipStream_t st, const double* G, double* F, double* Linv, int ld, int CB, int RT, int* flags,
-                  int* info, const int* ctr, const DowndateArgs& dd, int* claim, double* hs, int lenient) {
+                  int* info, const int* ctr, const DowndateArgs& dd, int* claim, double* hs, int lenient, int home) {
     // k_sweep_rl: block 0 is the chain workgroup; `hs` (>= 2 CB tiles) carries what the chain rows feed it; the CB flags
     // behind the abort word (`claim`) say so
-    if (sweep_rl_enabled() && CB <= 9)
-        k_sweep_rl<N, FUSED, 9><<<grid + 1, 256, 0, st>>>(G, F, Linv, ld, CB, RT, flags, info, ctr, dd, hs, lenient);
-    else if (sweep_rl_enabled() && CB <= 17)
-        k_sweep_rl<N, FUSED, 17><<<grid + 1, 256, 0, st>>>(G, F, Linv, ld, CB, RT, flags, info, ctr, dd, hs, lenient);
+    // XL (row blocks of S on the chain workgroup's XCD: blocks 8 s, the blocks between them empty)
+    const bool xl = home >= 0;
+    unsigned xgrid = 8u * (unsigned)(CB - 1) + 1u;
+    for (unsigned left = grid - (unsigned)CB; left > 0; ++xgrid)  // the other workgroups, skipping the blocks = 0 mod 8
+        if (xgrid % 8u != 0u) --left;
+    xgrid += (unsigned)(xl ? home : 0);
+    if (sweep_rl_enabled() && CB <= 9) {
+        if (xl) k_sweep_rl<N, FUSED, 9, true><<<xgrid, 256, 0, st>>>(G, F, Linv, ld, CB, RT, flags, info, ctr, dd, hs, lenient, home);
+        else k_sweep_rl<N, FUSED, 9, false><<<grid + 1, 256, 0, st>>>(G, F, Linv, ld, CB, RT, flags, info, ctr, dd, hs, lenient, home);
+    } else if (sweep_rl_enabled() && CB <= 17) {
+        if (xl) k_sweep_rl<N, FUSED, 17, true><<<xgrid, 256, 0, st>>>(G, F, Linv, ld, CB, RT, flags, info, ctr, dd, hs, lenient, home);
+        else k_sweep_rl<N, FUSED, 17, false><<<grid + 1, 256, 0, st>>>(G, F, Linv, ld, CB, RT, flags, info, ctr, dd, hs, lenient, home);
+    }
     else  // (a 33-tile row block no longer fits the register file: measured 1280 us against 666 at N = 1024)
         k_sweep<N, FUSED><<<grid, 256, 0, st>>>(G, F, Linv, ld, CB, RT, flags, info, ctr, dd, claim, hs, lenient);
 }
@@ -2554,12 +2867,12 @@ int launch_step(pnmol_filter* f, const double* Pin, const double* min, double fr
         dd.vrows = 0;  // (the vector ops are done by the row-block workgroups of the sweep themselves)
         if constexpr (N <= 3)
             launch_sweep<N, true>(f->RT + pairs, st, f->G, f->F, f->Linv, mp, f->CB, f->RT, f->flags, f->info, f->ctr, dd,
-                                  f->flags + f->RT + f->CB + 1, f->hs_scratch, f->p32 ? 2 : 0);
+                                  f->flags + f->RT + f->CB + 1, f->hs_scratch, f->p32 ? 2 : 0, f->xcd_home);
     } else {
         if (f->sweep_mode == 1) {
             // K3': the sweep alone as one dataflow launch
             launch_sweep<N, false>(f->RT, st, f->G, f->F, f->Linv, mp, f->CB, f->RT, f->flags, f->info, f->ctr, dd,
-                                   f->flags + f->RT + f->CB + 1, f->hs_scratch, 0);
+                                   f->flags + f->RT + f->CB + 1, f->hs_scratch, 0, f->xcd_home);
         } else {
             k_diag0<<<1, 128, 0, st>>>(f->G, f->F, f->Linv, mp, f->info, f->sdiag, f->ctr);
             // K3: right-looking sweep, one launch per 32-column panel
@@ -2772,7 +3085,7 @@ int run_cov_sqrtm_sweep(pnmol_filter* f, const double* Gc, double* Fc, double* L
     DowndateArgs dd{};
     const int cb = Dq / NB;
     launch_sweep<N, false>(cb, f->ctx->stream, Gc, Fc, Linvc, Dq, cb, cb, f->flags, f->info_err, f->one, dd,
-                           f->flags + 2 * cb + 1, cb <= 17 && sweep_rl_enabled() ? feedc : f->hs_scratch, 1);
+                           f->flags + 2 * cb + 1, cb <= 17 && sweep_rl_enabled() ? feedc : f->hs_scratch, 1, f->xcd_home);
     return 0;
 }
 
@@ -2785,7 +3098,7 @@ int run_error_model_sweep(pnmol_filter* f, const MeasModel& mm) {
                                                                                                          f->Rdense, mm, Dp, f->p32);
     DowndateArgs dd{};
     launch_sweep<N, false>(f->RT, st, f->G, f->F, f->Linv, mp, f->CB, f->RT, f->flags, f->info_err, f->one, dd,
-                           f->flags + f->RT + f->CB + 1, f->hs_scratch, f->p32 ? 2 : 0);
+                           f->flags + f->RT + f->CB + 1, f->hs_scratch, f->p32 ? 2 : 0, f->xcd_home);
     return 0;
 }
 
@@ -2952,6 +3265,13 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
     FCHK(hipMalloc(&f->part, sizeof(double) * 3 * mp));
     FCHK(hipMalloc(&f->ctr, sizeof(int)));
     if (const char* gc = std::getenv("PNMOL_HIP_GRAPH_CHUNK")) f->graph_chunk = std::atoi(gc) / 2 * 2;
+    {
+        static std::atomic<int> next_home{0};
+        const int others = live_filters.fetch_add(1);
+        f->counted = true;
+        const bool xl = sweep_xl_mode() < 0 ? others == 0 : sweep_xl_mode() == 1;
+        f->xcd_home = xl ? next_home.fetch_add(1) % 8 : -1;
+    }
     FCHK(hipMalloc(&f->sdiag, sizeof(double) * (mp + 1)));
     // k_sweep: row[RT], diag[CB], abort, claim[CB*CB];  k_sweep_rl: rl_flags();  the Cholesky factor of a whole
     // covariance (pnmol_state_get_cov_sqrtm) runs a square sweep of up to Dp/32 blocks on the same words
@@ -2997,6 +3317,7 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
 
 int pnmol_filter_destroy(pnmol_filter* f) {
     if (!f) return -1;
+    if (f->counted) live_filters.fetch_sub(1);
     hipSetDevice(f->ctx->device);
     drop_graphs(f);
     if (f->ctr) hipFree(f->ctr);

@@ -26,6 +26,10 @@ for J in range(CB):
     a = us(st[384 + J])
     nxt = us(st[384 + J + 1])[0] if J + 1 < CB else float("nan")
     print(f"J={J:2d} start {a[0]:7.2f} | factor {a[1]-a[0]:5.2f} | inv {a[6]-a[1]:5.2f} | barrier {a[2]-max(a[1],a[6]):5.2f} (at {a[2]:7.2f}) | trsm {a[3]-a[2]:5.2f} | syrk {nxt-a[3]:5.2f} | period {nxt-a[0]:5.2f}")
+clk = st[384:384 + CB, 4].astype(float)
+wall = st[384:384 + CB, 0].astype(float)
+print("shader clock of the chain workgroup's CU between diagonal blocks (MHz):",
+      " ".join(f"{(clk[i+1]-clk[i])/(wall[i+1]-wall[i])*100:.0f}" for i in range(CB - 1)))
 rows = us(st[1:1 + RT])
 chain_feed = rows[1:CB, 1]
 print("chain rows: fed at", " ".join(f"{x:.1f}" for x in chain_feed))
