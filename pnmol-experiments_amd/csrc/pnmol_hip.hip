@@ -1304,6 +1304,8 @@ struct DowndateArgs {
     const int* last_ctr;  // step counter value of the last step of the call
     double A1[MAXN * MAXN], Q1[MAXN * MAXN];
     int p32;              // the covariance is fp32 (pnmol_filter_desc.dtype = 1): fp32 accumulators on v_mfma_f32_16x16x4_f32
+    int last_ksteps;      // MFMA k-steps (of 8) of the LAST column block of W that hold real columns; 0 = all
+                          // (m = 514 = 16 * 32 + 2: columns 2 .. 31 of block 16 are padding, exactly zero in W)
 };
 
 // accumulator / MFMA of the down-date in the covariance's element type
@@ -1393,13 +1395,17 @@ __device__ __forceinline__ void sweep_downdate_body(SweepLds& L, const DowndateA
             frag_ld(fa[a], W + ((long)a * dd.dp + J * NB + qr * 16 + fr) * ld + (long)j * NB + 8 * fk);
             frag_ld(fb[a], W + ((long)a * dd.dp + K * NB + qc * 16 + fr) * ld + (long)j * NB + 8 * fk);
         }
+        // (k-step s of the permuted inner index covers columns s, 8 + s, 16 + s, 24 + s of the block)
+        const int smax = (j + 1 == CB && dd.last_ksteps > 0) ? dd.last_ksteps : 8;
 #pragma unroll
         for (int s = 0; s < 8; ++s)
+            if (s < smax) {
 #pragma unroll
-            for (int a = 0; a < N; ++a)
+                for (int a = 0; a < N; ++a)
 #pragma unroll
-                for (int b = 0; b < N; ++b)
-                    acc[a][b] = AccOf<PT>::mfma_neg(fa[a].v[s], fb[b].v[s], acc[a][b]);
+                    for (int b = 0; b < N; ++b)
+                        acc[a][b] = AccOf<PT>::mfma_neg(fa[a].v[s], fb[b].v[s], acc[a][b]);
+            }
     }
     SWEEP_STAMP(1);
     // epilogue: the tile, diag(P), and (J != K) the mirror image, transposed through wave-private LDS so that it
@@ -1954,7 +1960,8 @@ __device__ __forceinline__ void relay_wait_range_ge(const int* p, int cnt, int n
 // ds_read_b128.  An LDS-DMA instruction writes 64 x 16 B contiguously, so the image is row-major without padding and the
 // bank conflicts of 16 lanes reading 16 rows at one column are avoided by XOR-swizzling the 16-byte column index with the
 // row on the SOURCE address: slot (row, g ^ row) holds columns 2g, 2g+1 of the row.
-constexpr int RING = 4;
+constexpr int RING = 3;
+constexpr int RING_LINV = RING, RING_NEWEST = RING + 1;  // two more slots per wave: prefetched L_jj^-1 and tile (j+1, j)
 // one 16-byte LDS-DMA per lane: LDS[lds_dst + 16 lane] = *gsrc   (M0 is written and restored in the same statement)
 __device__ __forceinline__ void lds_dma16(const double* gsrc, unsigned lds_dst) {
     unsigned keep;
@@ -2134,7 +2141,7 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
         ChainLds C;
     } lds;
     SweepLds& L = lds.L;
-    __shared__ __attribute__((aligned(16))) double bulk_ring[4][RING][16 * NB];  // per wave: RING half tiles (4 KB each)
+    __shared__ __attribute__((aligned(16))) double bulk_ring[4][RING + 2][16 * NB];  // per wave: half tiles (4 KB each)
     const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = w >> 1, wc = w & 1, fr = l & 15, fk = l >> 4;
     const RlFlags fl = rl_flags(RT, CB);
@@ -2232,12 +2239,18 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
     // this wave's bulk operand ring and its lanes' source offsets (element units) inside a tile, per DMA instruction
     const double* ringw = &bulk_ring[w][0][0];
     const unsigned ring0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)ringw);
-    int roff[4];
+    int roff[4], roffL[4];  // (roffL: the same inside a tile of Linv, leading dimension NB)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int row = 4 * c + (l >> 4);
         roff[c] = (wc * 16 + row) * ld + 2 * ((l & 15) ^ row);
+        roffL[c] = (wc * 16 + row) * NB + 2 * ((l & 15) ^ row);
     }
+    // A row block that lags behind the chain workgroup (all rows of W and of the identity block, the late rows of S) finds
+    // L_jj^-1 and the newest tile (j+1, j) published long before it needs them: each wave then fetches its half of them by
+    // LDS-DMA a phase early (L_jj^-1 before the bulk update of step j, the newest tile at the end of step j), instead of
+    // loading them when the step gets there (0.3-0.5 us of exposed latency each, 17 times).
+    bool pre_b0 = false;
     // XL: a row block of S that does share the chain workgroup's XCD takes L^-1 and the newest tile from the L2 (flags
     // fdiagL / fnewL) and feeds through it
     bool local = false;
@@ -2277,10 +2290,16 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
 #pragma unroll
             for (int s = 0; s < 8; ++s) ax.v[s] = sXp[(wr * 16 + fr) * TLD + 8 * fk + s];
             // tile (j, j-1), from the chain workgroup
-            relay_progress(fnew, CB - 1, [](int) { return 1; }, j, known_new, &L.rnew, fabort, ww, w, l);
-            SWEEP_TRACE(j, 1);
             Frag8 b0;
-            frag_ld(b0, F + ((long)j * NB + wc * 16 + fr) * ld + (long)(j - 1) * NB + 8 * fk);
+            if (pre_b0) {  // (on its way since the end of step j-1)
+                SWEEP_TRACE(j, 1);
+                ring_wait(0);
+                ring_frag(b0, ringw + 512 * RING_NEWEST, fr, fk);
+            } else {
+                relay_progress(fnew, CB - 1, [](int) { return 1; }, j, known_new, &L.rnew, fabort, ww, w, l);
+                SWEEP_TRACE(j, 1);
+                frag_ld(b0, F + ((long)j * NB + wc * 16 + fr) * ld + (long)(j - 1) * NB + 8 * fk);
+            }
             SWEEP_TRACE_VM(j, 7);
 #pragma unroll
             for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ax.v[s], b0.v[s], acc, 0, 0, 0);
@@ -2317,6 +2336,14 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
         for (int r = 0; r < 4; ++r) sS[offC + 4 * r * TLD] = -acc[r];
         __syncthreads();  // S_j complete
         SWEEP_TRACE(j, 2);
+        bool pre_l = false;
+        {
+            const int seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&L.rdiag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (seen >= j + 1 && seen != (1 << 30)) {
+                ring_fill(Linv + (long)j * NB * NB, roffL, ring0 + 4096u * RING_LINV);
+                pre_l = true;
+            }
+        }
         const int tl = ntiles - 1;
         const bool bulk = j >= 1 && j + 1 < ntiles;
         // (3) panel j-1 on the tiles j+1 .. ntiles-1; the slots move down by one.  Done BEFORE the wait for L_jj^-1: its
@@ -2371,7 +2398,12 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
         relay_progress(fdiag, CB, [](int) { return 1; }, j + 1, known_diag, &L.rdiag, fabort, ww, w, l);
         SWEEP_TRACE(j, 5);
         Frag8 bl;
-        frag_ld(bl, Linv + (long)j * NB * NB + (wc * 16 + fr) * NB + 8 * fk);
+        if (pre_l) {
+            ring_wait(0);
+            ring_frag(bl, ringw + 512 * RING_LINV, fr, fk);
+        } else {
+            frag_ld(bl, Linv + (long)j * NB * NB + (wc * 16 + fr) * NB + 8 * fk);
+        }
         d4 x = {0, 0, 0, 0};
 #pragma unroll
         for (int s = 0; s < 8; ++s)
@@ -2393,7 +2425,14 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
                                                             sXj[(wc * 16 + fr) * TLD + 8 * fk + s], accD, 0, 0, 0);
         }
         SWEEP_TRACE(j, 3);
-        SWEEP_TRACE(j, 4);
+        pre_b0 = false;
+        if (j + 1 < ntiles) {
+            const int seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&L.rnew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (seen >= j + 1 && seen != (1 << 30)) {
+                ring_fill(F + (long)(j + 1) * NB * ld + (long)j * NB, roff, ring0 + 4096u * RING_NEWEST);
+                pre_b0 = true;
+            }
+        }
         SWEEP_TRACE(j, 6);
     }
     if (!chain) flag_tile(ntiles - 1);  // (a chain row has flagged its last own tile in its feed step)
@@ -2827,6 +2866,13 @@ void launch_sweep(unsigned grid, hipStream_t st, const double* G, double* F, dou
         k_sweep<N, FUSED><<<grid, 256, 0, st>>>(G, F, Linv, ld, CB, RT, flags, info, ctr, dd, claim, hs, lenient);
 }
 
+inline bool short_last_panel() {  // PNMOL_HIP_SHORT_LAST=0: A/B switch
+    static const int on = [] {
+        const char* e = std::getenv("PNMOL_HIP_SHORT_LAST");
+        return e ? std::atoi(e) : 1;
+    }();
+    return on != 0;
+}
 template <int N>
 int launch_step(pnmol_filter* f, const double* Pin, const double* min, double frame_dt, double dt, double* Pout,
                 double* mout, double* varout, bool record, StepKind kind) {
@@ -2857,7 +2903,9 @@ int launch_step(pnmol_filter* f, const double* Pin, const double* min, double fr
     const bool have_sq = (f->Sqinv != nullptr && f->sq_dt == dt);
     VecArgs va{f->mpred, f->F + ((long)mp + Dp) * mp, f->F + rowI0 * mp, f->zbuf, have_sq ? f->Sqinv : nullptr,
                mout, f->part};
-    DowndateArgs dd{f->Ppred, Pout, varout, dp, 0, va, kind == STEP_FULL ? nullptr : f->Ppred, f->Kg, f->last_ctr, {}, {}, f->p32};
+    const int nreal = f->m - NB * (f->CB - 1);  // real columns of the last column block
+    DowndateArgs dd{f->Ppred, Pout, varout, dp, 0, va, kind == STEP_FULL ? nullptr : f->Ppred, f->Kg, f->last_ctr, {}, {}, f->p32,
+                    (nreal < 8 && short_last_panel()) ? nreal : 0};
     std::memcpy(dd.A1, f->iwp.A1, sizeof(dd.A1));
     std::memcpy(dd.Q1, f->iwp.Q1, sizeof(dd.Q1));
     if (f->sweep_mode == 2) {

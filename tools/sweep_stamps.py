@@ -41,13 +41,13 @@ if nd:
     print(f"down-date WGs {nd}: start min/max {d[:,0].min():.2f}/{d[:,0].max():.2f}  end min/median/max {d[:,5].min():.2f}/{np.median(d[:,5]):.2f}/{d[:,5].max():.2f}")
     print(f"  last block done min/median/max {d[:,1].min():.2f}/{np.median(d[:,1]):.2f}/{d[:,1].max():.2f}; epilogue stores issued "
           f"{np.median(d[:,2] - d[:,1]):.2f} us later (median), vector ops + exit {np.median(d[:,5] - d[:,2]):.2f} us")
-print("per-step trace of one row block (us): step-start, row[j] seen, newest operand loaded, S_j done(barrier), diag seen, after X_j/accD, bulk done, step end"
+print("per-step trace of one row block (us): step-start, newest tile known, newest operand loaded, S_j done(barrier), bulk done, diag known, after X_j/accD, step end"
       "   [feed step: start, seen, loaded, stores issued, drained, flag set]")
 for j in range(CB):
     a = us(st[256 + j])
     if st[256 + j, 0] <= 0:
         continue
-    print(f"j={j:2d} " + " ".join(f"{a[i]:8.2f}" if st[256 + j, i] > 0 else "       -" for i in (0, 1, 7, 2, 5, 3, 4, 6)))
+    print(f"j={j:2d} " + " ".join(f"{a[i]:8.2f}" if st[256 + j, i] > 0 else "       -" for i in (0, 1, 7, 2, 4, 5, 3, 6)))
 
 print("publishing wave of the same block (us): X_j complete (after barrier), stores issued, bulk done, stores drained + flag")
 for j in range(CB):
