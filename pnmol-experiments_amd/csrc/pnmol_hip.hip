@@ -1332,7 +1332,9 @@ struct AccOf<float> {
 // (qr, qc) owns the 16x16 quadrant (qr, qc) of each block: its accumulators start as the P- tile, every 32-column
 // block j of W is subtracted as soon as the 2 N row blocks of W it needs have published step j (row[] counters), so
 // the down-date rides along with the sweep on CUs the sweep does not use instead of following it.
-template <int N, typename PT>
+// SHORT_LAST: honour dd.last_ksteps (k_sweep_rl only: in k_sweep the guarded MFMA loop costs the large problems 20 %,
+// N = 1024 797 us against 660)
+template <int N, typename PT, bool SHORT_LAST>
 __device__ __forceinline__ void sweep_downdate_body(SweepLds& L, const DowndateArgs& dd, const double* F, int ld, int CB,
                                                     int RBS, const int* frow, int* fabort, int* info, int pair, int tid,
                                                     int l, int w, int slot) {
@@ -1396,10 +1398,10 @@ __device__ __forceinline__ void sweep_downdate_body(SweepLds& L, const DowndateA
             frag_ld(fb[a], W + ((long)a * dd.dp + K * NB + qc * 16 + fr) * ld + (long)j * NB + 8 * fk);
         }
         // (k-step s of the permuted inner index covers columns s, 8 + s, 16 + s, 24 + s of the block)
-        const int smax = (j + 1 == CB && dd.last_ksteps > 0) ? dd.last_ksteps : 8;
+        const int smax = (SHORT_LAST && j + 1 == CB && dd.last_ksteps > 0) ? dd.last_ksteps : 8;
 #pragma unroll
         for (int s = 0; s < 8; ++s)
-            if (s < smax) {
+            if (!SHORT_LAST || s < smax) {
 #pragma unroll
                 for (int a = 0; a < N; ++a)
 #pragma unroll
@@ -1495,12 +1497,12 @@ __device__ __forceinline__ void sweep_downdate_body(SweepLds& L, const DowndateA
     SWEEP_STAMP(5);
 }
 
-template <int N>
+template <int N, bool SHORT_LAST = false>
 __device__ __forceinline__ void sweep_downdate_role(SweepLds& L, const DowndateArgs& dd, const double* F, int ld, int CB,
                                                     int RBS, const int* frow, int* fabort, int* info, int pair, int tid,
                                                     int l, int w, int slot) {
-    if (dd.p32) sweep_downdate_body<N, float>(L, dd, F, ld, CB, RBS, frow, fabort, info, pair, tid, l, w, slot);
-    else sweep_downdate_body<N, double>(L, dd, F, ld, CB, RBS, frow, fabort, info, pair, tid, l, w, slot);
+    if (dd.p32) sweep_downdate_body<N, float, SHORT_LAST>(L, dd, F, ld, CB, RBS, frow, fabort, info, pair, tid, l, w, slot);
+    else sweep_downdate_body<N, double, SHORT_LAST>(L, dd, F, ld, CB, RBS, frow, fabort, info, pair, tid, l, w, slot);
 }
 
 template <int N, bool FUSED, bool CHAINHELP = FUSED>
@@ -2198,7 +2200,7 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
             }
             __syncthreads();
             SWEEP_STAMP(0);
-            sweep_downdate_role<N>(L, dd, F, ld, CB, CB, frow, fabort, info, I - RT, tid, l, w, *ctr - 1);
+            sweep_downdate_role<N, true>(L, dd, F, ld, CB, CB, frow, fabort, info, I - RT, tid, l, w, *ctr - 1);
             return;
         }
     }

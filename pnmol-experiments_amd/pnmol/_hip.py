@@ -4,6 +4,7 @@ There is no CPU fallback: if the library or a GPU is missing, the solver classes
 """
 
 import ctypes
+import weakref
 import os
 import pathlib
 
@@ -233,8 +234,13 @@ class Filter:
         self.handle = h
         self.d, self.n, self.nB, self.m = d, int(num_derivatives) + 1, nB, d + nB
         self.error_model_dt = None
+        self._states = weakref.WeakSet()   # live `State`s: a pnmol_state must be destroyed before its pnmol_filter
 
     def __del__(self):
+        # The cyclic garbage collector (and interpreter shutdown) finalises a filter and its states in ANY order: the
+        # states go first here, and a state whose filter is already gone does not touch the library (State.__del__).
+        for st in list(getattr(self, "_states", ())):
+            st._destroy()
         h, self.handle = getattr(self, "handle", None), None
         if h:
             self.lib.pnmol_filter_destroy(h)
@@ -329,11 +335,15 @@ class State:
             _handle = _vp()
             self.ctx.check(self.lib.pnmol_state_create(flt.handle, ctypes.byref(_handle)), "pnmol_state_create")
         self.handle = _handle
+        flt._states.add(self)
+
+    def _destroy(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h and getattr(self.filter, "handle", None):
+            self.lib.pnmol_state_destroy(h)
 
     def __del__(self):
-        h, self.handle = getattr(self, "handle", None), None
-        if h:
-            self.lib.pnmol_state_destroy(h)
+        self._destroy()
 
     def clone(self):
         h = _vp()

@@ -60,8 +60,12 @@ class _WhiteNoiseEK1Base(pdefilter.PDEFilter):
         self._gram = gamma @ gamma.T
         self._error_models = {}
 
-    # True: the reference's own two `update_sqrt` calls, on the device (below); False: closed form on the host
-    initialize_on_device = os.environ.get("PNMOL_INIT_ON_DEVICE", "0") == "1"
+    # True: the reference's own two `update_sqrt` calls, on the device (below); False: closed form on the host (O(d^3) LAPACK);
+    # None (default; PNMOL_INIT_ON_DEVICE=0/1 overrides): on the device from n d >= 4096 on, where the host form takes
+    # seconds (64x64 mesh: 18 s against 10 s), closed form below that (its rounding-level entries are what the
+    # factor-level tests are tuned to; both match the oracle at the north-star tolerances)
+    initialize_on_device = {"0": False, "1": True}.get(os.environ.get("PNMOL_INIT_ON_DEVICE", ""), None)
+    INIT_ON_DEVICE_FROM = 4096
 
     def _initialize_on_device(self, pde, gamma):
         """white.py:12-80 as written: prior kron(Gamma, c I) -> update_sqrt on y0 (nugget 1e-10) -> update_sqrt on the
@@ -99,7 +103,10 @@ class _WhiteNoiseEK1Base(pdefilter.PDEFilter):
         self.iwp, self.E0, self.E1, gamma = self.initialize_iwp(pde)
         self._bind(pde, gamma)
         n, d = self.num_derivatives + 1, pde.L.shape[0]
-        if self.initialize_on_device:
+        on_device = self.initialize_on_device
+        if on_device is None:
+            on_device = n * d >= self.INIT_ON_DEVICE_FROM
+        if on_device:
             mean, dev = self._initialize_on_device(pde, gamma)
             return pdefilter.PDEFilterState(t=pde.t0, y=rv.DeviceMultivariateNormal(mean, dev), error_estimate=None,
                                             reference_state=None, diffusion_squared_local=[])
