@@ -362,3 +362,20 @@ def test_stop_at_adjusts_the_step_grid(hip_ctx):
     assert sol.info == osol.info
     omeans, ostds = oracle.read_mean_and_std(osol, osolver.E0)
     assert_mean_std_parity(sol.mean[:, 0], sol.marginal_std[:, 0], omeans, ostds)
+
+
+@pytest.mark.parametrize("N", [96, 256])
+def test_filters_alive_together_agree_bit_for_bit(hip_ctx, N):
+    """The first live filter of a process runs the sweep in its XCD-local layout (chain workgroup and S row blocks on one
+    XCD, hand-over through its L2), later ones in the spread layout (write-through hand-over): the arithmetic is the same,
+    so three filters of one problem that are alive together must agree bit for bit -- whichever layouts they got."""
+    import gc
+    gc.collect()
+    dt, K = 2.0 ** -7, 12
+    runs, keep = [], []
+    for _ in range(3):
+        pde, solver, _, _ = make_pair(N, 2, dt, K)
+        keep.append(solver)                      # (keeps the device filter alive)
+        runs.append(solver.solve_marginals(pde))
+    for r in runs[1:]:
+        assert np.array_equal(runs[0][1], r[1]) and np.array_equal(runs[0][2], r[2]) and np.array_equal(runs[0][3], r[3])
