@@ -2283,9 +2283,8 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
                 __hip_atomic_fetch_add(flags + fl.fcol + l * fl.CBp + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
-    for (int j = 0; j < ntiles; ++j) {
-        // (1) the newest panel on tile j
-        d4 acc = n[0];
+    // (1) of a step: the newest panel (j-1) on tile j
+    auto newest_panel = [&](int j, d4& acc) {
         SWEEP_TRACE(j, 0);
         if (j >= 1) {
             const double* sXp = ((j - 1) & 1) ? L.sP[0] : L.sX;
@@ -2307,32 +2306,10 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
             for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ax.v[s], b0.v[s], acc, 0, 0, 0);
             flag_tile(j - 1);  // (b0 has arrived: so have the stores of tile j-1, issued before its load)
         }
-        if (j > last) {  // chain row, j = I - 1: feed the chain workgroup (S tile, then -D'), and that is it
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                L.sS[0][offC + 4 * r * TLD] = -acc[r];
-                L.sS[1][offC + 4 * r * TLD] = accD[r];
-            }
-            __syncthreads();
-            if (XL && local) {
-                wt_rows_from_lds<2, 0>(rfeed, (unsigned)((2 * I) * NB * NB * 8), NB, L.sS[0], 8 * w, l);
-                wt_rows_from_lds<2, 0>(rfeed, (unsigned)((2 * I + 1) * NB * NB * 8), NB, L.sS[1], 8 * w, l);
-            } else {
-                wt_rows_from_lds<2>(rfeed, (unsigned)((2 * I) * NB * NB * 8), NB, L.sS[0], 8 * w, l);
-                wt_rows_from_lds<2>(rfeed, (unsigned)((2 * I + 1) * NB * NB * 8), NB, L.sS[1], 8 * w, l);
-            }
-            SWEEP_TRACE(j, 2);
-            drain_vmem();
-            SWEEP_TRACE(j, 3);
-            __syncthreads();
-            if (tid == 0) {
-                if (XL && local) l2_flag_st(rflags, fl.ffeed + I, 1);
-                else flag_st(ffeed + I, 1);
-            }
-            SWEEP_TRACE(j, 4);
-            SWEEP_STAMP(1);
-            break;
-        }
+    };
+    for (int j = 0; j <= last; ++j) {
+        d4 acc = n[0];
+        newest_panel(j, acc);
         double* sS = L.sS[j & 1];
 #pragma unroll
         for (int r = 0; r < 4; ++r) sS[offC + 4 * r * TLD] = -acc[r];
@@ -2436,6 +2413,37 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
             }
         }
         SWEEP_TRACE(j, 6);
+    }
+    if (chain) {
+        // j = I - 1: tile I-1 with all panels but the last goes to the chain workgroup together with -D'.  (Behind the loop, not
+        // a pass of it: the loop's back-edge moves all accumulator registers, 0.5 us that sat on the critical cycle
+        // L^-1 -> X -> feed -> next factorisation.)
+        const int j = I - 1;
+        d4 acc = n[0];
+        newest_panel(j, acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                L.sS[0][offC + 4 * r * TLD] = -acc[r];
+                L.sS[1][offC + 4 * r * TLD] = accD[r];
+            }
+            __syncthreads();
+            if (XL && local) {
+                wt_rows_from_lds<2, 0>(rfeed, (unsigned)((2 * I) * NB * NB * 8), NB, L.sS[0], 8 * w, l);
+                wt_rows_from_lds<2, 0>(rfeed, (unsigned)((2 * I + 1) * NB * NB * 8), NB, L.sS[1], 8 * w, l);
+            } else {
+                wt_rows_from_lds<2>(rfeed, (unsigned)((2 * I) * NB * NB * 8), NB, L.sS[0], 8 * w, l);
+                wt_rows_from_lds<2>(rfeed, (unsigned)((2 * I + 1) * NB * NB * 8), NB, L.sS[1], 8 * w, l);
+            }
+            SWEEP_TRACE(j, 2);
+            drain_vmem();
+            SWEEP_TRACE(j, 3);
+            __syncthreads();
+            if (tid == 0) {
+                if (XL && local) l2_flag_st(rflags, fl.ffeed + I, 1);
+                else flag_st(ffeed + I, 1);
+            }
+            SWEEP_TRACE(j, 4);
+            SWEEP_STAMP(1);
     }
     if (!chain) flag_tile(ntiles - 1);  // (a chain row has flagged its last own tile in its feed step)
     if (!chain) {
