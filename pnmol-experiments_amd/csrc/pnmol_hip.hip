@@ -2422,28 +2422,28 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
         d4 acc = n[0];
         newest_panel(j, acc);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                L.sS[0][offC + 4 * r * TLD] = -acc[r];
-                L.sS[1][offC + 4 * r * TLD] = accD[r];
-            }
-            __syncthreads();
-            if (XL && local) {
-                wt_rows_from_lds<2, 0>(rfeed, (unsigned)((2 * I) * NB * NB * 8), NB, L.sS[0], 8 * w, l);
-                wt_rows_from_lds<2, 0>(rfeed, (unsigned)((2 * I + 1) * NB * NB * 8), NB, L.sS[1], 8 * w, l);
-            } else {
-                wt_rows_from_lds<2>(rfeed, (unsigned)((2 * I) * NB * NB * 8), NB, L.sS[0], 8 * w, l);
-                wt_rows_from_lds<2>(rfeed, (unsigned)((2 * I + 1) * NB * NB * 8), NB, L.sS[1], 8 * w, l);
-            }
-            SWEEP_TRACE(j, 2);
-            drain_vmem();
-            SWEEP_TRACE(j, 3);
-            __syncthreads();
-            if (tid == 0) {
-                if (XL && local) l2_flag_st(rflags, fl.ffeed + I, 1);
-                else flag_st(ffeed + I, 1);
-            }
-            SWEEP_TRACE(j, 4);
-            SWEEP_STAMP(1);
+        for (int r = 0; r < 4; ++r) {
+            L.sS[0][offC + 4 * r * TLD] = -acc[r];
+            L.sS[1][offC + 4 * r * TLD] = accD[r];
+        }
+        __syncthreads();
+        if (XL && local) {
+            wt_rows_from_lds<2, 0>(rfeed, (unsigned)((2 * I) * NB * NB * 8), NB, L.sS[0], 8 * w, l);
+            wt_rows_from_lds<2, 0>(rfeed, (unsigned)((2 * I + 1) * NB * NB * 8), NB, L.sS[1], 8 * w, l);
+        } else {
+            wt_rows_from_lds<2>(rfeed, (unsigned)((2 * I) * NB * NB * 8), NB, L.sS[0], 8 * w, l);
+            wt_rows_from_lds<2>(rfeed, (unsigned)((2 * I + 1) * NB * NB * 8), NB, L.sS[1], 8 * w, l);
+        }
+        SWEEP_TRACE(j, 2);
+        drain_vmem();
+        SWEEP_TRACE(j, 3);
+        __syncthreads();
+        if (tid == 0) {
+            if (XL && local) l2_flag_st(rflags, fl.ffeed + I, 1);
+            else flag_st(ffeed + I, 1);
+        }
+        SWEEP_TRACE(j, 4);
+        SWEEP_STAMP(1);
     }
     if (!chain) flag_tile(ntiles - 1);  // (a chain row has flagged its last own tile in its feed step)
     if (!chain) {

@@ -35,6 +35,8 @@ chain_feed = rows[1:CB, 1]
 print("chain rows: fed at", " ".join(f"{x:.1f}" for x in chain_feed))
 bulk = rows[CB:RT]
 print(f"other row blocks {RT-CB}: start min/max {bulk[:,0].min():.2f}/{bulk[:,0].max():.2f}  end min/max {bulk[:,5].min():.2f}/{bulk[:,5].max():.2f}")
+print("  end of every other row block (us), in row order [z, W rows..., identity rows...]:", " ".join(f"{x:.0f}" for x in bulk[:, 5]))
+print("  their starts of the last step (stamp 2: vector ops begin):", " ".join(f"{x:.0f}" for x in bulk[:, 2]))
 nd = int((st[1 + RT:256, 0] > 0).sum())
 if nd:
     d = us(st[1 + RT:1 + RT + nd])
