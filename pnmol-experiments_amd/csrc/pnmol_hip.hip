@@ -2284,7 +2284,7 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
         }
     };
     // (1) of a step: the newest panel (j-1) on tile j
-    auto newest_panel = [&](int j, d4& acc) {
+    auto newest_panel = [&](int j, d4& acc, bool flag_previous) {
         SWEEP_TRACE(j, 0);
         if (j >= 1) {
             const double* sXp = ((j - 1) & 1) ? L.sP[0] : L.sX;
@@ -2304,12 +2304,12 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
             SWEEP_TRACE_VM(j, 7);
 #pragma unroll
             for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ax.v[s], b0.v[s], acc, 0, 0, 0);
-            flag_tile(j - 1);  // (b0 has arrived: so have the stores of tile j-1, issued before its load)
+            if (flag_previous) flag_tile(j - 1);  // (b0 has arrived: so have the stores of tile j-1, issued before its load)
         }
     };
     for (int j = 0; j <= last; ++j) {
         d4 acc = n[0];
-        newest_panel(j, acc);
+        newest_panel(j, acc, true);
         double* sS = L.sS[j & 1];
 #pragma unroll
         for (int r = 0; r < 4; ++r) sS[offC + 4 * r * TLD] = -acc[r];
@@ -2395,7 +2395,11 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
         // stores, competing with the other waves' operand loads, took 2.3-3.8 us to issue, and everybody waited for that
         // wave at the next barrier
         SWEEP_TRACE_W2(j, 0);
-        wt_rows_from_lds<2>(rF, (unsigned)((((long)I * NB) * ld + (long)j * NB) * 8), ld, sXj, 8 * w, l);
+        // (a row block of S sends the tile of its LAST ordinary step behind its feed: the feed's loads and its drain wait for
+        // every older operation of the wave, and a write-through store takes 1-1.5 us to complete -- on the cycle
+        // L^-1 -> X -> feed -> next factorisation)
+        if (!(chain && j == last))
+            wt_rows_from_lds<2>(rF, (unsigned)((((long)I * NB) * ld + (long)j * NB) * 8), ld, sXj, 8 * w, l);
         SWEEP_TRACE_W2(j, 1);
         if (chain) {
 #pragma unroll
@@ -2420,7 +2424,7 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
         // L^-1 -> X -> feed -> next factorisation.)
         const int j = I - 1;
         d4 acc = n[0];
-        newest_panel(j, acc);
+        newest_panel(j, acc, false);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             L.sS[0][offC + 4 * r * TLD] = -acc[r];
@@ -2444,6 +2448,11 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
         }
         SWEEP_TRACE(j, 4);
         SWEEP_STAMP(1);
+        if (last >= 0) {  // tile (I, I-2), held back above (still in its LDS buffer: the feed used sS only)
+            const double* sXl = (last & 1) ? L.sP[0] : L.sX;
+            wt_rows_from_lds<2>(rF, (unsigned)((((long)I * NB) * ld + (long)last * NB) * 8), ld, sXl, 8 * w, l);
+            flag_tile(last);
+        }
     }
     if (!chain) flag_tile(ntiles - 1);  // (a chain row has flagged its last own tile in its feed step)
     if (!chain) {
