@@ -927,7 +927,11 @@ __device__ long long pnmol_sweep_stamp[512][8];
 #define CHAIN_TRACE_W(J, slot, wave) do { if (l == 0 && w == (wave)) pnmol_sweep_stamp[384 + (J)][slot] = wall_clock64(); } while (0)
 // shader-clock counter (s_memtime) next to the constant 100 MHz one: their ratio is the clock the chain workgroup's CU ran at
 #define CHAIN_TRACE_CLK(J, slot) do { if (tid == 0) pnmol_sweep_stamp[384 + (J)][slot] = clock64(); } while (0)
+#define PNMOL_DD_DBG 1
+// one down-date workgroup (pair 60): rows 448 + j
+#define DD_TRACE(j, slot) do { if (tid == 0 && pair == 60) pnmol_sweep_stamp[448 + (j)][slot] = wall_clock64(); } while (0)
 #else
+#define DD_TRACE(j, slot) do {} while (0)
 #define CHAIN_TRACE_CLK(J, slot) do {} while (0)
 #define SWEEP_TRACE_VM(j, slot) do {} while (0)
 #define SWEEP_TRACE_W2(j, slot) do {} while (0)
@@ -1334,6 +1338,11 @@ struct AccOf<float> {
 // the down-date rides along with the sweep on CUs the sweep does not use instead of following it.
 // SHORT_LAST: honour dd.last_ksteps (k_sweep_rl only: in k_sweep the guarded MFMA loop costs the large problems 20 %,
 // N = 1024 797 us against 660)
+#ifdef PNMOL_DD_DBG
+__device__ __forceinline__ void pnmol_dd_avail_dbg(int j, int avail, bool loaded) { pnmol_sweep_stamp[448 + j][3] = avail; pnmol_sweep_stamp[448 + j][4] = loaded; }
+#else
+__device__ __forceinline__ void pnmol_dd_avail_dbg(int, int, bool) {}
+#endif
 template <int N, typename PT, bool SHORT_LAST>
 __device__ __forceinline__ void sweep_downdate_body(SweepLds& L, const DowndateArgs& dd, const double* F, int ld, int CB,
                                                     int RBS, const int* frow, int* fabort, int* info, int pair, int tid,
@@ -1357,46 +1366,61 @@ __device__ __forceinline__ void sweep_downdate_body(SweepLds& L, const DowndateA
             for (int r = 0; r < 4; ++r)
                 acc[a][b][r] = Ppred[((long)a * dd.dp + J * NB + qr * 16 + AccOf<PT>::row(fk, r)) * Dp + (long)b * dd.dp + K * NB + qc * 16 + fr];
     int avail = 0;  // column blocks of W known to be complete for all 2 N row blocks
-    for (int j = 0; j < CB; ++j) {
-        if (j >= avail) {
-            __syncthreads();
-            if (w == 0) {
-                int mn = 0;
-                if (!L.dead) {
-                    for (int spins = 0;; ++spins) {
-                        int v = 1 << 30;
-                        if (l < 2 * N) {
-                            const int a = l >> 1, tile = (l & 1) ? K : J;
-                            v = flag_ld(frow + RBS + a * T32 + tile);
-                        }
-#pragma unroll
-                        for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-                        mn = v;
-                        if (mn > j) break;
-                        if (spins > SWEEP_SPIN_LIMIT || flag_ld(fabort)) {
-                            if (l == 0) {
-                                L.dead = 1;
-                                flag_st(fabort, 1);
-                            }
-                            mn = 1 << 30;
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(4);
+    // wait until column block j is there (all threads)
+    auto wait_for = [&](int j) {
+        if (j < avail) return;
+        __syncthreads();
+        if (w == 0) {
+            int mn = 0;
+            if (!L.dead) {
+                for (int spins = 0;; ++spins) {
+                    int v = 1 << 30;
+                    if (l < 2 * N) {
+                        const int a = l >> 1, tile = (l & 1) ? K : J;
+                        v = flag_ld(frow + RBS + a * T32 + tile);
                     }
-                } else {
-                    mn = 1 << 30;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+                    mn = v;
+                    if (mn > j) break;
+                    if (spins > SWEEP_SPIN_LIMIT || flag_ld(fabort)) {
+                        if (l == 0) {
+                            L.dead = 1;
+                            flag_st(fabort, 1);
+                        }
+                        mn = 1 << 30;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(4);
                 }
-                if (l == 0) L.seen[0] = mn;
+            } else {
+                mn = 1 << 30;
             }
-            __syncthreads();
-            avail = L.seen[0];
+            if (l == 0) L.seen[0] = mn;
         }
-        Frag8 fa[N], fb[N];
+        __syncthreads();
+        avail = L.seen[0];
+    };
+    auto load_panel = [&](int j, Frag8 (&fa)[N], Frag8 (&fb)[N]) {
 #pragma unroll
         for (int a = 0; a < N; ++a) {
             frag_ld(fa[a], W + ((long)a * dd.dp + J * NB + qr * 16 + fr) * ld + (long)j * NB + 8 * fk);
             frag_ld(fb[a], W + ((long)a * dd.dp + K * NB + qc * 16 + fr) * ld + (long)j * NB + 8 * fk);
         }
+    };
+    // One column block: its fragments are in (fa, fb) or are loaded now; the NEXT block's are requested before this block's
+    // 72 MFMAs whenever it is known to be complete already (a workgroup that has fallen behind the sweep -- they all
+    // do at the end: the last panels arrive every 6 us and took 6 us each with the load latency exposed -- catches up at the
+    // MFMA rate).  Returns whether (na, nb) hold block j+1.
+    auto panel = [&](int j, bool loaded, Frag8 (&fa)[N], Frag8 (&fb)[N], Frag8 (&na)[N], Frag8 (&nb)[N]) {
+        DD_TRACE(j, 0);
+        if (!loaded) {
+            wait_for(j);
+            DD_TRACE(j, 1);
+            load_panel(j, fa, fb);
+        }
+        const bool next = j + 1 < CB && j + 1 < avail;
+        if (next) load_panel(j + 1, na, nb);
         // (k-step s of the permuted inner index covers columns s, 8 + s, 16 + s, 24 + s of the block)
         const int smax = (SHORT_LAST && j + 1 == CB && dd.last_ksteps > 0) ? dd.last_ksteps : 8;
 #pragma unroll
@@ -1408,6 +1432,30 @@ __device__ __forceinline__ void sweep_downdate_body(SweepLds& L, const DowndateA
                     for (int b = 0; b < N; ++b)
                         acc[a][b] = AccOf<PT>::mfma_neg(fa[a].v[s], fb[b].v[s], acc[a][b]);
             }
+        DD_TRACE(j, 2);
+        if (tid == 0 && pair == 60) pnmol_dd_avail_dbg(j, avail, loaded);
+        return next;
+    };
+    if constexpr (SHORT_LAST) {  // (k_sweep_rl; the large problems' k_sweep keeps the plain loop below)
+        Frag8 fa0[N], fb0[N], fa1[N], fb1[N];
+        bool loaded = false;
+        for (int j = 0; j < CB; j += 2) {
+            loaded = panel(j, loaded, fa0, fb0, fa1, fb1);
+            if (j + 1 < CB) loaded = panel(j + 1, loaded, fa1, fb1, fa0, fb0);
+        }
+    } else {
+        for (int j = 0; j < CB; ++j) {
+            wait_for(j);
+            Frag8 fa[N], fb[N];
+            load_panel(j, fa, fb);
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int a = 0; a < N; ++a)
+#pragma unroll
+                    for (int b = 0; b < N; ++b)
+                        acc[a][b] = AccOf<PT>::mfma_neg(fa[a].v[s], fb[b].v[s], acc[a][b]);
+        }
     }
     SWEEP_STAMP(1);
     // epilogue: the tile, diag(P), and (J != K) the mirror image, transposed through wave-private LDS so that it
@@ -1954,6 +2002,15 @@ __device__ __forceinline__ void relay_wait_range_ge(const int* p, int cnt, int n
     asm volatile("" ::: "memory");
 }
 
+// hipcc (ROCm 7.2) hazard: where a chain of MFMAs ends a conditional block, the s_nop that must separate the last MFMA
+// from a v_accvgpr_read / v_accvgpr_mov of its result can end up BEHIND the first reads in the block the branch joins
+// (seen twice in k_sweep_rl: accumulator element 3 -- rows fk + 12 of a tile -- stale, only in builds without the timeline
+// stamps, whose LDS reads hide it).  Wait states by hand behind such chains; nothing may be scheduled across them.
+__device__ __forceinline__ void mfma_result_guard() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
 // ---- bulk operand ring of k_sweep_rl ------------------------------------------------------------------------------
 // The rank-32 update of a row block reads one 32x32 tile of L per tile it updates; as fragment loads to registers with one
 // tile of look-ahead (all the register file allows) a tile took 0.45 us against 0.21 us of MFMA: one miss latency each.
@@ -2304,12 +2361,13 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
             SWEEP_TRACE_VM(j, 7);
 #pragma unroll
             for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ax.v[s], b0.v[s], acc, 0, 0, 0);
+            mfma_result_guard();
             if (flag_previous) flag_tile(j - 1);  // (b0 has arrived: so have the stores of tile j-1, issued before its load)
         }
     };
     for (int j = 0; j <= last; ++j) {
         d4 acc = n[0];
-        newest_panel(j, acc, true);
+        newest_panel(j, acc, chain || j != ntiles - 1);  // (tile CB-2 of the other rows is flagged eagerly, below)
         double* sS = L.sS[j & 1];
 #pragma unroll
         for (int r = 0; r < 4; ++r) sS[offC + 4 * r * TLD] = -acc[r];
@@ -2406,6 +2464,13 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
             for (int s = 0; s < 8; ++s)
                 accD = __builtin_amdgcn_mfma_f64_16x16x4f64(sXj[(wr * 16 + fr) * TLD + 8 * fk + s],
                                                             sXj[(wc * 16 + fr) * TLD + 8 * fk + s], accD, 0, 0, 0);
+            mfma_result_guard();
+        } else if (j == ntiles - 2) {
+            // The last tile but one is flagged NOW (1-1.5 us of write-through drain that this row block would spend waiting
+            // for the chain's last block anyway), not at the next step's first load as the others: the down-date workgroups
+            // got block CB-2 of W only when the chain's last factorisation was through, 4-5 us late, and finished 10 us behind
+            // the sweep.
+            flag_tile(j);
         }
         SWEEP_TRACE(j, 3);
         pre_b0 = false;

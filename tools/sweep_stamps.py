@@ -57,3 +57,10 @@ for j in range(CB):
         continue
     a = us(st[320 + j])
     print(f"j={j:2d} " + " ".join(f"{a[i]:8.2f}" for i in range(4)) + f"   | drain {a[3]-a[2]:5.2f}")
+
+print("one down-date workgroup (pair 60), per column block (us): entered, [waited until], MFMAs issued | avail, fragments prefetched")
+for j in range(CB):
+    a = st[448 + j]
+    if a[0] <= 0:
+        continue
+    print(f"j={j:2d} {us(a[0]):8.2f} " + (f"{us(a[1]):8.2f}" if a[1] > 0 else "       -") + f" {us(a[2]):8.2f} | {int(a[3])} {int(a[4])}")
