@@ -2002,6 +2002,61 @@ __device__ __forceinline__ void relay_wait_range_ge(const int* p, int cnt, int n
     asm volatile("" ::: "memory");
 }
 
+// out[q] = sum_i base[(row0 + q) * mp + i] * vec[i], q = 0 .. 7, by one wave (every lane gets the sums).  All loads of a
+// 256-column slice are issued back to back (see vecops_rowsR).
+__device__ __forceinline__ void rows8_dot(const double* __restrict__ base, long row0, int mp, const double* __restrict__ vec,
+                                          double (&out)[8], int l) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) out[q] = 0.0;
+    for (int i0 = l; i0 < mp; i0 += 256) {
+        double wv[8][4], xv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int i = i0 + 64 * t;
+            const int ii = i < mp ? i : mp - 1;
+            xv[t] = i < mp ? vec[ii] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) wv[q][t] = base[(row0 + q) * mp + ii];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) out[q] += wv[q][t] * xv[t];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) out[q] += __shfl_xor(out[q], o);
+}
+// The vector ops of eight rows of [W; Ls^-T] (see vecops_rows) with one matrix row read per output row: rows of W need W r
+// only, and for the rows of Ls^-T the error-model product Sq^-1 z -- a constant matrix times a vector that is known when
+// the sweep starts -- comes in as bq (made at the start of the launch by the same wave, off the tail).
+__device__ __forceinline__ void vecops_rows8(const VecArgs& va, const double* __restrict__ W, int mp, long Dp, long r0,
+                                             const double* bq /* LDS, 8 values */, int l) {
+    double a[8];
+    if (r0 < Dp) {
+        rows8_dot(W, r0, mp, va.r, a, l);
+        if (l < 8) {
+            double mine = a[0];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) mine = (l == q) ? a[q] : mine;
+            va.mout[r0 + l] = va.mpred[r0 + l] - mine;
+        }
+    } else {
+        const long k0 = r0 - Dp;
+        rows8_dot(va.LinvT, k0, mp, va.z, a, l);
+        if (l < 8) {
+            double mine = a[0];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) mine = (l == q) ? a[q] : mine;
+            const double bm = bq[l];
+            const long k = k0 + l;
+            va.part[k] = va.r[k] * va.r[k];
+            va.part[mp + k] = mine * mine;
+            va.part[2 * mp + k] = va.z[k] * bm;
+        }
+    }
+}
 // hipcc (ROCm 7.2) hazard: where a chain of MFMAs ends a conditional block, the s_nop that must separate the last MFMA
 // from a v_accvgpr_read / v_accvgpr_mov of its result can end up BEHIND the first reads in the block the branch joins
 // (seen twice in k_sweep_rl: accumulator element 3 -- rows fk + 12 of a tile -- stale, only in builds without the timeline
@@ -2310,6 +2365,19 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
     // LDS-DMA a phase early (L_jj^-1 before the bulk update of step j, the newest tile at the end of step j), instead of
     // loading them when the step gets there (0.3-0.5 us of exposed latency each, 17 times).
     bool pre_b0 = false;
+    // identity rows (rows of Ls^-T): the error-model product (Sq^-1 z)_k of this wave's eight rows, now (vecops_rows8)
+    // (parked in L.sd[8 w + q], which the row blocks of this kernel do not use otherwise: no registers across the sweep)
+    if constexpr (FUSED) {
+        const int RBW = RT - 2 * CB - 1, zb = CB + RBW;
+        if (!chain && I > zb) {
+            double bq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (dd.va.Sqinv != nullptr) rows8_dot(dd.va.Sqinv, (long)(I - zb - 1) * NB + 8 * w, ld, dd.va.z, bq, l);
+            if (l == 0) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) L.sd[8 * w + q] = bq[q];
+            }
+        }
+    }
     // XL: a row block of S that does share the chain workgroup's XCD takes L^-1 and the newest tile from the L2 (flags
     // fdiagL / fnewL) and feeds through it
     bool local = false;
@@ -2530,7 +2598,7 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
                 const long row0 = (I < zb ? (long)(I - CB) * NB : Dp + (long)(I - zb - 1) * NB) + 8 * w;
                 const double* W = F + (long)ld * ld;
                 SWEEP_STAMP(2);
-                vecops_rowsR<8>(dd.va, W, ld, Dp, row0, row0 + 8, l);
+                vecops_rows8(dd.va, W, ld, Dp, row0, L.sd + 8 * w, l);
             }
         }
     }
