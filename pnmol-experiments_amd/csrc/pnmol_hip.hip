@@ -2364,6 +2364,13 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
     // L_jj^-1 and the newest tile (j+1, j) published long before it needs them: each wave then fetches its half of them by
     // LDS-DMA a phase early (L_jj^-1 before the bulk update of step j, the newest tile at the end of step j), instead of
     // loading them when the step gets there (0.3-0.5 us of exposed latency each, 17 times).
+    // tiles of a row of W / Ls^-T that are flagged right behind their stores instead of at the next step's first load: where
+    // the row block has slack (little left to update), so that the down-date workgroups -- MFMA-bound, 5.5 us per column
+    // block -- get the last blocks of W a chain period earlier and finish closer behind the sweep
+#ifndef PNMOL_EAGER_TILES
+#define PNMOL_EAGER_TILES 6
+#endif
+    constexpr int EAGER_TILES = PNMOL_EAGER_TILES;
     bool pre_b0 = false;
     // identity rows (rows of Ls^-T): the error-model product (Sq^-1 z)_k of this wave's eight rows, now (vecops_rows8)
     // (parked in L.sd[8 w + q], which the row blocks of this kernel do not use otherwise: no registers across the sweep)
@@ -2435,7 +2442,7 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
     };
     for (int j = 0; j <= last; ++j) {
         d4 acc = n[0];
-        newest_panel(j, acc, chain || j != ntiles - 1);  // (tile CB-2 of the other rows is flagged eagerly, below)
+        newest_panel(j, acc, chain || j - 1 < ntiles - EAGER_TILES);  // (the other rows flag their last tiles eagerly, below)
         double* sS = L.sS[j & 1];
 #pragma unroll
         for (int r = 0; r < 4; ++r) sS[offC + 4 * r * TLD] = -acc[r];
@@ -2533,8 +2540,8 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
                 accD = __builtin_amdgcn_mfma_f64_16x16x4f64(sXj[(wr * 16 + fr) * TLD + 8 * fk + s],
                                                             sXj[(wc * 16 + fr) * TLD + 8 * fk + s], accD, 0, 0, 0);
             mfma_result_guard();
-        } else if (j == ntiles - 2) {
-            // The last tile but one is flagged NOW (1-1.5 us of write-through drain that this row block would spend waiting
+        } else if (j >= ntiles - EAGER_TILES && j <= ntiles - 2) {
+            // The last tiles (but the very last, which is flagged behind the loop) are flagged NOW (1-1.5 us of write-through drain that this row block would spend waiting
             // for the chain's last block anyway), not at the next step's first load as the others: the down-date workgroups
             // got block CB-2 of W only when the chain's last factorisation was through, 4-5 us late, and finished 10 us behind
             // the sweep.
