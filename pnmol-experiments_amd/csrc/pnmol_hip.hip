@@ -2062,6 +2062,9 @@ __device__ __forceinline__ void vecops_rows8(const VecArgs& va, const double* __
 // (seen twice in k_sweep_rl: accumulator element 3 -- rows fk + 12 of a tile -- stale, only in builds without the timeline
 // stamps, whose LDS reads hide it).  Wait states by hand behind such chains; nothing may be scheduled across them.
 __device__ __forceinline__ void mfma_result_guard() {
+#ifdef PNMOL_NO_MFMA_GUARD  // (tools/mfma_hazard_scan.py must then find the reads in the ISA)
+    return;
+#endif
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
