@@ -1852,21 +1852,27 @@ __global__ __launch_bounds__(256) void k_sweep(const double* __restrict__ G, dou
 // so the work per step SHRINKS with j, every tile product is 8 MFMAs per wave with one operand stream, and nothing but
 //     tile j:  n_j += X_{j-1} L_{j,j-1}^T  ->  X_j = S_j L_jj^-T  [ -> D -= X_j X_j^T -> factor ]
 // waits for the newest data.  The slots rotate (slot u holds tile j + u: the update of slot u is written to slot u-1), so
-// the step loop is a plain run-time loop over fixed registers.  Waits are per wave (every wave polls the word itself):
-// two workgroup barriers per step (S_j complete in LDS, X_j complete in LDS), none around the polls.
+// the step loop is a plain run-time loop over fixed registers -- at the price of a register move per accumulator at the
+// loop's back-edge (0.5 us per step), which is why the feed of a row block of S is NOT a pass of that loop.  Two
+// workgroup barriers per step (S_j complete in LDS, X_j complete in LDS), none around the polls: wave 0 polls and relays
+// through LDS.  The update's operands stream through a per-wave LDS ring filled by LDS-DMA; with XL the chain workgroup
+// and the row blocks of S share an XCD and hand over through its L2.  DESIGN.md section 3a'' has the measurements.
 // ------------------------------------------------------------------------------------------
 // Flags of k_sweep_rl.  A poll is an uncached (sc1) load served at the memory side, ~12 ns each PER ADDRESS: with every
 // wave of 83 workgroups polling the same line (and the abort word beside it) a flag that had been set was seen 2-5 us
 // late.  So: ONE wave per workgroup polls global memory and relays through LDS to the other three; the flags everybody
 // waits for at the same time exist in RL_REP copies on lines of their own (a consumer polls copy blockIdx % RL_REP); the
-// update of step j waits for ONE counter per column panel instead of up to 16 row flags; the abort word is read every
-// 64th poll only.
+// update of step j waits for ONE counter per column panel instead of up to 16 row flags (a row block of S for exactly the
+// rows it reads); one poll reads a whole flag array and wave 0 remembers the finished prefix (relay_progress); the abort
+// word is read every 64th poll only.
 //   frow[RT]          row block I has published its own tiles 0 .. frow[I]-1       (down-date role; the r^T block)
 //   fabort            somebody timed out
 //   ffeed[CB]         row block J has fed S_{J,J-1} and -D'_J to the chain workgroup
 //   fdiag[RL_REP][CBp]  L_JJ^-1 is published                                       (chain workgroup)
 //   fnew[RL_REP][CBp]   tile (J+1, J) of F is published                            (chain workgroup, ~1 us later)
 //   fcol[RL_REP][CBp]   number of chain rows that have published their own tile p  (atomic adds)
+//   fxcc              1 + XCC id of the chain workgroup (XL)
+//   fdiagL[CBp], fnewL[CBp]  copies of fdiag / fnew that are stored plainly, for the pollers on the chain workgroup's XCD (XL)
 constexpr int RL_REP = 8;
 struct RlFlags {
     int frow, fabort, fxcc, ffeed, fdiag, fnew, fcol, fdiagL, fnewL, CBp, total;
