@@ -1873,9 +1873,10 @@ __global__ __launch_bounds__(256) void k_sweep(const double* __restrict__ G, dou
 //   fcol[RL_REP][CBp]   number of chain rows that have published their own tile p  (atomic adds)
 //   fxcc              1 + XCC id of the chain workgroup (XL)
 //   fdiagL[CBp], fnewL[CBp]  copies of fdiag / fnew that are stored plainly, for the pollers on the chain workgroup's XCD (XL)
+//   frowL[CBp]        frow of the row blocks of S for the same pollers; ahead of frow for a row's last ordinary tile (see there)
 constexpr int RL_REP = 8;
 struct RlFlags {
-    int frow, fabort, fxcc, ffeed, fdiag, fnew, fcol, fdiagL, fnewL, CBp, total;
+    int frow, fabort, fxcc, ffeed, fdiag, fnew, fcol, fdiagL, fnewL, frowL, CBp, total;
 };
 __host__ __device__ inline RlFlags rl_flags(int RT, int CB) {
     const int RTp = (RT + 31) / 32 * 32, CBp = (CB + 31) / 32 * 32;
@@ -1890,7 +1891,8 @@ __host__ __device__ inline RlFlags rl_flags(int RT, int CB) {
     f.fcol = f.fnew + RL_REP * CBp;
     f.fdiagL = f.fcol + RL_REP * CBp;  // copies of fdiag / fnew that live in the chain workgroup's XCD (see XL below)
     f.fnewL = f.fdiagL + CBp;
-    f.total = f.fnewL + CBp;
+    f.frowL = f.fnewL + CBp;  // frow of the row blocks of S, for the pollers on the chain workgroup's XCD (XL)
+    f.total = f.frowL + CBp;
     return f;
 }
 // The XCC (XCD) this wave runs on.
@@ -2327,7 +2329,7 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
     }
     if (chain && I == 0) return;  // (block (0,0) is the chain workgroup's own)
     if (tid == 0) {
-        L.dead = 0, L.pubcnt = 0, L.rdiag = 0, L.rnew = 0, L.rcol = 0, L.rzb = 0;
+        L.dead = 0, L.pub = 0, L.pubcnt = 0, L.rdiag = 0, L.rnew = 0, L.rcol = 0, L.rzb = 0;
         L.seen[0] = 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // one invalidate per workgroup (see k_sweep)
     }
@@ -2420,6 +2422,10 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
         if (l == 0) lastw = __hip_atomic_fetch_add(&L.pubcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 4 * t + 3;
         if (__builtin_amdgcn_readfirstlane(lastw)) {
             if (l == 0) flag_st(frow + I, t + 1);
+            if (XL && chain && l == 0) {  // (a row block that is not on the chain workgroup's XCD after all: written through)
+                if (local) l2_flag_st(rflags, fl.frowL + I, t + 1);
+                else flag_st(flags + fl.frowL + I, t + 1);
+            }
             if (chain && l < RL_REP)
                 __hip_atomic_fetch_add(flags + fl.fcol + l * fl.CBp + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -2473,7 +2479,7 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
         if (bulk) {
             // A row block of S reads tiles (t, j-1) of the rows t = j+1 .. I-1 only, all of them ahead of it: it waits for
             // exactly those (frow[t] >= j); the others wait for the panel's counter (CB-1-j publications)
-            if (chain) relay_progress_min(frow + j + 1, I - 1 - j, j, known_col, &L.rcol, fabort, ww, w, l);
+            if (chain) relay_progress_min((XL && local ? flags + fl.frowL : frow) + j + 1, I - 1 - j, j, known_col, &L.rcol, fabort, ww, w, l);
             else relay_progress(fcol, CB - 1, [CB](int k) { return CB - 2 - k; }, j, known_col, &L.rcol, fabort, ww, w, l);
             const int cnt = tl - j;  // tiles j+1 .. tl
             const double* Lt = F + (long)(j - 1) * NB + (long)(j + 1) * NB * ld;  // tile (j+1, j-1); + k * NB * ld
@@ -2537,11 +2543,18 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
         // stores, competing with the other waves' operand loads, took 2.3-3.8 us to issue, and everybody waited for that
         // wave at the next barrier
         SWEEP_TRACE_W2(j, 0);
-        // (a row block of S sends the tile of its LAST ordinary step behind its feed: the feed's loads and its drain wait for
-        // every older operation of the wave, and a write-through store takes 1-1.5 us to complete -- on the cycle
-        // L^-1 -> X -> feed -> next factorisation)
-        if (!(chain && j == last))
-            wt_rows_from_lds<2>(rF, (unsigned)((((long)I * NB) * ld + (long)j * NB) * 8), ld, sXj, 8 * w, l);
+        if (XL && local && j == last) {
+            // The tile of a row block's LAST ordinary step, X_{I,I-2}, is what the next row block of S needs for its own
+            // last-but-one update: X_{I,I-2} -> row I+1: update, TRSM -> X_{I+1,I-1} -> ... is a cycle of its own, and with
+            // the tile flagged behind this row's feed it ran through the whole feed (6.4 us per block, the chain workgroup
+            // idle for 2 us of them).  So: into the L2 first, flagged for the pollers on this XCD as soon as that has drained.
+            wt_rows_from_lds<2, 0>(rF, (unsigned)((((long)I * NB) * ld + (long)j * NB) * 8), ld, sXj, 8 * w, l);
+            drain_vmem();
+            int lastw = 0;
+            if (l == 0) lastw = __hip_atomic_fetch_add(&L.pub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 3;
+            if (__builtin_amdgcn_readfirstlane(lastw) && l == 0) l2_flag_st(rflags, fl.frowL + I, j + 1);
+        }
+        wt_rows_from_lds<2>(rF, (unsigned)((((long)I * NB) * ld + (long)j * NB) * 8), ld, sXj, 8 * w, l);
         SWEEP_TRACE_W2(j, 1);
         if (chain) {
 #pragma unroll
@@ -2597,11 +2610,12 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
         }
         SWEEP_TRACE(j, 4);
         SWEEP_STAMP(1);
-        if (last >= 0) {  // tile (I, I-2), held back above (still in its LDS buffer: the feed used sS only)
-            const double* sXl = (last & 1) ? L.sP[0] : L.sX;
-            wt_rows_from_lds<2>(rF, (unsigned)((((long)I * NB) * ld + (long)last * NB) * 8), ld, sXl, 8 * w, l);
-            flag_tile(last);
-        }
+        // Tile (I, I-2), stored in the last ordinary step, is flagged HERE: the feed's drain has covered its write-through
+        // stores, so the flag costs no wait of its own and is up as early as it can be without one -- the next row block
+        // of S needs that tile for its last-but-one update, i.e. it sits on the cycle  L^-1 -> X -> feed -> factorisation
+        // through a second path (flagged lazily or behind a publication of its own it arrived 1.5-2 us later and the
+        // next feed with it).
+        if (last >= 0) flag_tile(last);
     }
     if (!chain) flag_tile(ntiles - 1);  // (a chain row has flagged its last own tile in its feed step)
     if (!chain) {
