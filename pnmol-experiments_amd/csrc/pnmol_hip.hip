@@ -2431,7 +2431,7 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
         }
     };
     // (1) of a step: the newest panel (j-1) on tile j
-    auto newest_panel = [&](int j, d4& acc, bool flag_previous) {
+    auto newest_panel = [&](int j, d4& acc, bool flag_previous, bool with_syrk) {
         SWEEP_TRACE(j, 0);
         if (j >= 1) {
             const double* sXp = ((j - 1) & 1) ? L.sP[0] : L.sX;
@@ -2448,6 +2448,16 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
                 SWEEP_TRACE(j, 1);
                 frag_ld(b0, F + ((long)j * NB + wc * 16 + fr) * ld + (long)(j - 1) * NB + 8 * fk);
             }
+            if (with_syrk) {
+                // (the feed) D' -= X_{j-1} X_{j-1}^T, left out of step j-1: its MFMAs are issued behind the request for the
+                // newest tile and in front of its use (pinned), 0.45 us behind a 0.45 us load on the cycle
+                // L^-1 -> X -> feed -> chain
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < 8; ++s)
+                    accD = __builtin_amdgcn_mfma_f64_16x16x4f64(ax.v[s], sXp[(wc * 16 + fr) * TLD + 8 * fk + s], accD, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             SWEEP_TRACE_VM(j, 7);
 #pragma unroll
             for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ax.v[s], b0.v[s], acc, 0, 0, 0);
@@ -2457,7 +2467,7 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
     };
     for (int j = 0; j <= last; ++j) {
         d4 acc = n[0];
-        newest_panel(j, acc, chain || j - 1 < ntiles - EAGER_TILES);  // (the other rows flag their last tiles eagerly, below)
+        newest_panel(j, acc, chain || j - 1 < ntiles - EAGER_TILES, false);  // (the other rows flag their last tiles eagerly, below)
         double* sS = L.sS[j & 1];
 #pragma unroll
         for (int r = 0; r < 4; ++r) sS[offC + 4 * r * TLD] = -acc[r];
@@ -2543,25 +2553,19 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
         // stores, competing with the other waves' operand loads, took 2.3-3.8 us to issue, and everybody waited for that
         // wave at the next barrier
         SWEEP_TRACE_W2(j, 0);
-        if (XL && local && j == last) {
-            // The tile of a row block's LAST ordinary step, X_{I,I-2}, is what the next row block of S needs for its own
-            // last-but-one update: X_{I,I-2} -> row I+1: update, TRSM -> X_{I+1,I-1} -> ... is a cycle of its own, and with
-            // the tile flagged behind this row's feed it ran through the whole feed (6.4 us per block, the chain workgroup
-            // idle for 2 us of them).  So: into the L2 first, flagged for the pollers on this XCD as soon as that has drained.
-            wt_rows_from_lds<2, 0>(rF, (unsigned)((((long)I * NB) * ld + (long)j * NB) * 8), ld, sXj, 8 * w, l);
-            drain_vmem();
-            int lastw = 0;
-            if (l == 0) lastw = __hip_atomic_fetch_add(&L.pub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 3;
-            if (__builtin_amdgcn_readfirstlane(lastw) && l == 0) l2_flag_st(rflags, fl.frowL + I, j + 1);
-        }
-        wt_rows_from_lds<2>(rF, (unsigned)((((long)I * NB) * ld + (long)j * NB) * 8), ld, sXj, 8 * w, l);
+        // (a row block of S stores the tile of its LAST ordinary step behind its feed, see there: nothing between X and the
+        // feed that the feed does not need)
+        if (!(chain && j == last))
+            wt_rows_from_lds<2>(rF, (unsigned)((((long)I * NB) * ld + (long)j * NB) * 8), ld, sXj, 8 * w, l);
         SWEEP_TRACE_W2(j, 1);
         if (chain) {
+            if (j != last) {  // (the last one is made in the feed, behind the request for the newest tile)
 #pragma unroll
-            for (int s = 0; s < 8; ++s)
-                accD = __builtin_amdgcn_mfma_f64_16x16x4f64(sXj[(wr * 16 + fr) * TLD + 8 * fk + s],
-                                                            sXj[(wc * 16 + fr) * TLD + 8 * fk + s], accD, 0, 0, 0);
-            mfma_result_guard();
+                for (int s = 0; s < 8; ++s)
+                    accD = __builtin_amdgcn_mfma_f64_16x16x4f64(sXj[(wr * 16 + fr) * TLD + 8 * fk + s],
+                                                                sXj[(wc * 16 + fr) * TLD + 8 * fk + s], accD, 0, 0, 0);
+                mfma_result_guard();
+            }
         } else if (j >= ntiles - EAGER_TILES && j <= ntiles - 2) {
             // The last tiles (but the very last, which is flagged behind the loop) are flagged NOW (1-1.5 us of write-through drain that this row block would spend waiting
             // for the chain's last block anyway), not at the next step's first load as the others: the down-date workgroups
@@ -2586,7 +2590,7 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
         // L^-1 -> X -> feed -> next factorisation.)
         const int j = I - 1;
         d4 acc = n[0];
-        newest_panel(j, acc, false);
+        newest_panel(j, acc, false, true);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             L.sS[0][offC + 4 * r * TLD] = -acc[r];
@@ -2610,12 +2614,22 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
         }
         SWEEP_TRACE(j, 4);
         SWEEP_STAMP(1);
-        // Tile (I, I-2), stored in the last ordinary step, is flagged HERE: the feed's drain has covered its write-through
-        // stores, so the flag costs no wait of its own and is up as early as it can be without one -- the next row block
-        // of S needs that tile for its last-but-one update, i.e. it sits on the cycle  L^-1 -> X -> feed -> factorisation
-        // through a second path (flagged lazily or behind a publication of its own it arrived 1.5-2 us later and the
-        // next feed with it).
-        if (last >= 0) flag_tile(last);
+        // Tile (I, I-2), X of the last ordinary step (still in its LDS buffer: the feed used sS only), goes out now: the next
+        // row block of S needs it for its last-but-one update one chain period from now, the others later.  Into the L2
+        // first, flagged for the pollers on this XCD (frowL) as soon as that has drained; then written through.
+        if (last >= 0) {
+            const double* sXl = (last & 1) ? L.sP[0] : L.sX;
+            const unsigned org = (unsigned)((((long)I * NB) * ld + (long)last * NB) * 8);
+            if (XL && local) {
+                wt_rows_from_lds<2, 0>(rF, org, ld, sXl, 8 * w, l);
+                drain_vmem();
+                int lastw = 0;
+                if (l == 0) lastw = __hip_atomic_fetch_add(&L.pub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 3;
+                if (__builtin_amdgcn_readfirstlane(lastw) && l == 0) l2_flag_st(rflags, fl.frowL + I, last + 1);
+            }
+            wt_rows_from_lds<2>(rF, org, ld, sXl, 8 * w, l);
+            flag_tile(last);
+        }
     }
     if (!chain) flag_tile(ntiles - 1);  // (a chain row has flagged its last own tile in its feed step)
     if (!chain) {
