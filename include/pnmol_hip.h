@@ -18,6 +18,13 @@
  *     reference's `PDEFilterState` carries.
  *   - one ctx <-> one device <-> one HIP stream.  A ctx is not thread-safe; different
  *     ctxs are independent (one thread or process per GPU).
+ *   - Lifetimes: a handle keeps its parent alive.  Destroy in the order states -> filter(s) -> ctx.  A destroy call on
+ *     a parent that still has live children does NOTHING and returns -1 (`pnmol_last_error` says how many children are
+ *     left): `pnmol_filter_destroy` while any `pnmol_state` of the filter lives, `pnmol_ctx_destroy` while any
+ *     `pnmol_filter` / `pnmol_sqrt_filter` of the ctx lives, `pnmol_state_destroy` of the target of an unfinished
+ *     `pnmol_filter_steps_begin`.  The handle stays valid after a refused destroy; call it again once the children are gone.
+ *   - `pnmol_abi_version()` = 2 (1: before `pnmol_filter_desc.dtype`, the lifetime rule and `pnmol_filter_sweep_layout`).
+ *     Zero-initialise `pnmol_filter_desc`: unknown `dtype` values are rejected with -1.
  *   - dtype: fp64 (the reference runs with jax_enable_x64, src/pnmol/__init__.py:9-11); `pnmol_filter_desc.dtype = 1`
  *     keeps the covariance and its bulk kernels in fp32 (build-side option).
  */
@@ -36,7 +43,7 @@ typedef struct pnmol_state pnmol_state;   /* device-resident (mean, covariance, 
 int pnmol_abi_version(void);
 int pnmol_device_count(int* count);
 int pnmol_ctx_create(int device, pnmol_ctx** out);
-int pnmol_ctx_destroy(pnmol_ctx* ctx);
+int pnmol_ctx_destroy(pnmol_ctx* ctx); /* -1, nothing freed, while filters of ctx are alive (see Lifetimes) */
 int pnmol_ctx_synchronize(pnmol_ctx* ctx);
 const char* pnmol_last_error(pnmol_ctx* ctx);
 
@@ -70,7 +77,12 @@ typedef struct pnmol_filter_desc {
 } pnmol_filter_desc;
 
 int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_filter** out);
-int pnmol_filter_destroy(pnmol_filter* f);
+int pnmol_filter_destroy(pnmol_filter* f); /* -1, nothing freed, while states of f are alive (see Lifetimes) */
+/* Which sweep launch this filter's steps use (build-side diagnostic; no reference counterpart): *kernel = 0 per-panel
+ * launches, 1 left-looking dataflow kernel (wide matrices: N = 1024, 2-d meshes), 2 register-resident right-looking kernel
+ * (d + nB <= 544); *xcd_home = the XCD its critical workgroups are placed on (XCD-local layout: the first such filter alive on
+ * a device, or PNMOL_HIP_SWEEP_XL=1) or -1 (spread layout).  Timings of the two layouts differ; benchmarks report this. */
+int pnmol_filter_sweep_layout(const pnmol_filter* f, int* kernel, int* xcd_home);
 
 /* Step-invariant part of `estimate_error` (white.py:153-162) for step size dt:
  * Sq = H (Ql Ql^T) H^T + E E^T depends only on dt for a linear PDE.  The caller passes
@@ -95,7 +107,7 @@ int pnmol_filter_set_operator(pnmol_filter* f, const double* M_dds, const double
 
 /* states ----------------------------------------------------------------------------- */
 int pnmol_state_create(pnmol_filter* f, pnmol_state** out);
-int pnmol_state_destroy(pnmol_state* s);
+int pnmol_state_destroy(pnmol_state* s); /* -1 for the target of an unfinished pnmol_filter_steps_begin */
 int pnmol_state_clone(const pnmol_state* s, pnmol_state** out); /* reject/retry, pdefilter.py:192-223 */
 /* upload `PDEFilterState(t, y=(mean, cov))`; cov = cov_sqrtm @ cov_sqrtm.T (base/rv.py:12-14) */
 int pnmol_state_set(pnmol_state* s, double t, const double* mean_nd, const double* cov_DD);

@@ -1433,7 +1433,9 @@ __device__ __forceinline__ void sweep_downdate_body(SweepLds& L, const DowndateA
                         acc[a][b] = AccOf<PT>::mfma_neg(fa[a].v[s], fb[b].v[s], acc[a][b]);
             }
         DD_TRACE(j, 2);
+#ifdef PNMOL_SWEEP_STAMP
         if (tid == 0 && pair == 60) pnmol_dd_avail_dbg(j, avail, loaded);
+#endif
         return next;
     };
     if constexpr (SHORT_LAST) {  // (k_sweep_rl; the large problems' k_sweep keeps the plain loop below)
@@ -2954,7 +2956,9 @@ struct pnmol_filter {
     int sweep_mode = 2;    // PNMOL_HIP_SWEEP: 2 = k_sweep with the covariance down-date riding along in the same launch,
                            // 1 = k_sweep, then k_downdate; 0 = k_diag0 + one k_panel launch per panel, then k_downdate
     int ds = 0;  // spatial components of the state (= d, or 2d for the latent-force model [u; eps])
-    bool counted = false;  // this filter is in live_filters
+    bool counted = false;  // this filter is in live_rl_filters[device]
+    bool registered = false;  // this filter is counted in ctx->children
+    std::atomic<int> states{0};  // live pnmol_state objects of this filter (pnmol_filter_destroy refuses while > 0)
     int xcd_home = -1;  // k_sweep_rl: >= 0: XCD-local layout (XL), chain workgroup and S row blocks on this XCD; -1: spread layout
     int p32 = 0;        // pnmol_filter_desc.dtype = 1: covariances (state, predicted, Q) are stored and down-dated in fp32
     size_t psz = 8;     // bytes per covariance element
@@ -3039,7 +3043,9 @@ inline int sweep_xl_mode() {
     }();
     return mode;
 }
-std::atomic<int> live_filters{0};
+// live filters that launch k_sweep_rl, per device: the first one of a device gets the XCD-local layout (see pnmol_filter_create)
+constexpr int MAX_DEVICES = 64;
+std::atomic<int> live_rl_filters[MAX_DEVICES];
 template <int N, bool FUSED>
 void launch_sweep(unsigned grid, hipStream_t st, const double* G, double* F, double* Linv, int ld, int CB, int RT, int* flags,
                   int* info, const int* ctr, const DowndateArgs& dd, int* claim, double* hs, int lenient, int home) {
@@ -3350,7 +3356,7 @@ int run_error_model_sweep(pnmol_filter* f, const MeasModel& mm) {
 
 extern "C" {
 
-int pnmol_abi_version(void) { return 1; }
+int pnmol_abi_version(void) { return 2; }  // 2: pnmol_filter_desc.dtype, lifetime rule (refused destroys), pnmol_filter_sweep_layout
 
 int pnmol_device_count(int* count) {
     if (!count) return -1;
@@ -3381,6 +3387,10 @@ int pnmol_ctx_create(int device, pnmol_ctx** out) {
 
 int pnmol_ctx_destroy(pnmol_ctx* ctx) {
     if (!ctx) return -1;
+    if (ctx->children.load() != 0) {  // (lifetime rule, include/pnmol_hip.h: filters first)
+        ctx->err = "pnmol_ctx_destroy: " + std::to_string(ctx->children.load()) + " filter(s) of this ctx are still alive";
+        return -1;
+    }
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -3405,9 +3415,15 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
         ctx->err = "pnmol_filter_create: bad descriptor (need d>=1, 1<=nu<=3, non-null L/B/E_sqrtm/R_sqrtm/Gamma)";
         return -1;
     }
+    if (desc->dtype != 0 && desc->dtype != 1) {
+        ctx->err = "pnmol_filter_create: unknown dtype " + std::to_string(desc->dtype) + " (0 = fp64, 1 = fp32 covariance)";
+        return -1;
+    }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     pnmol_filter* f = new pnmol_filter();
     f->ctx = ctx;
+    ctx->children.fetch_add(1);
+    f->registered = true;
     f->d = d, f->ds = ds, f->nu = nu, f->n = n, f->nB = nB, f->m = d + nB;
     f->p32 = desc->dtype == 1, f->psz = f->p32 ? 4 : 8;
     f->dp = round_up(ds, NB), f->mp = round_up(f->m, NB);
@@ -3509,12 +3525,21 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
     FCHK(hipMalloc(&f->part, sizeof(double) * 3 * mp));
     FCHK(hipMalloc(&f->ctr, sizeof(int)));
     if (const char* gc = std::getenv("PNMOL_HIP_GRAPH_CHUNK")) f->graph_chunk = std::atoi(gc) / 2 * 2;
+    if (const char* e = std::getenv("PNMOL_HIP_SWEEP")) f->sweep_mode = std::atoi(e);
+    if (f->sweep_mode == 2 && n > 3) f->sweep_mode = 1;  // the fused down-date role is built for n <= 3
     {
-        static std::atomic<int> next_home{0};
-        const int others = live_filters.fetch_add(1);
-        f->counted = true;
-        const bool xl = sweep_xl_mode() < 0 ? others == 0 : sweep_xl_mode() == 1;
-        f->xcd_home = xl ? next_home.fetch_add(1) % 8 : -1;
+        // XCD-local layout (k_sweep_rl<.., XL>): only a filter that launches k_sweep_rl is counted, per device; unless
+        // PNMOL_HIP_SWEEP_XL forces it, the first such filter alive on its device gets the layout (pnmol_filter_sweep_layout
+        // reports what was chosen, so that timings are attributable).
+        static std::atomic<int> next_home[MAX_DEVICES];
+        const bool rl = sweep_rl_enabled() && f->CB <= 17 && f->sweep_mode >= 1;
+        if (rl) {
+            const int dv = ctx->device % MAX_DEVICES;
+            const int others = live_rl_filters[dv].fetch_add(1);
+            f->counted = true;
+            const bool xl = sweep_xl_mode() < 0 ? others == 0 : sweep_xl_mode() == 1;
+            f->xcd_home = xl ? next_home[dv].fetch_add(1) % 8 : -1;
+        }
     }
     FCHK(hipMalloc(&f->sdiag, sizeof(double) * (mp + 1)));
     // k_sweep: row[RT], diag[CB], abort, claim[CB*CB];  k_sweep_rl: rl_flags();  the Cholesky factor of a whole
@@ -3524,13 +3549,11 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
     FCHK(hipMalloc(&f->flags, sizeof(int) * f->nflags));
     FCHK(hipMemset(f->flags, 0, sizeof(int) * f->nflags));
     FCHK(hipMalloc(&f->hs_scratch, sizeof(double) * (size_t)std::max(f->CB * f->CB, 2 * f->CB + 2) * NB * NB));  // (also k_sweep_rl's feed tiles)
-    if (const char* e = std::getenv("PNMOL_HIP_SWEEP")) f->sweep_mode = std::atoi(e);
     if (const char* e = std::getenv("PNMOL_HIP_FUSE_PREDICT")) f->fuse_predict = std::atoi(e);
     FCHK(hipMalloc(&f->last_ctr, sizeof(int)));
     FCHK(hipMemset(f->last_ctr, 0, sizeof(int)));
     FCHK(hipMalloc(&f->tickets, sizeof(int)));
     FCHK(hipMemset(f->tickets, 0, sizeof(int)));
-    if (f->sweep_mode == 2 && n > 3) f->sweep_mode = 1;  // the fused down-date role is built for n <= 3
     if (f->p32 && f->sweep_mode != 2) {
         ctx->err = "pnmol_filter_create: dtype = fp32 covariance needs the fused sweep (num_derivatives <= 2, PNMOL_HIP_SWEEP unset)";
         return fail(-1);
@@ -3561,7 +3584,12 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
 
 int pnmol_filter_destroy(pnmol_filter* f) {
     if (!f) return -1;
-    if (f->counted) live_filters.fetch_sub(1);
+    if (f->states.load() != 0) {  // (lifetime rule, include/pnmol_hip.h: states first)
+        f->ctx->err = "pnmol_filter_destroy: " + std::to_string(f->states.load()) + " state(s) of this filter are still alive";
+        return -1;
+    }
+    if (f->counted) live_rl_filters[f->ctx->device % MAX_DEVICES].fetch_sub(1);
+    if (f->registered) f->ctx->children.fetch_sub(1);
     hipSetDevice(f->ctx->device);
     drop_graphs(f);
     if (f->ctr) hipFree(f->ctr);
@@ -3584,6 +3612,13 @@ int pnmol_filter_dims(const pnmol_filter* f, int* d, int* n, int* m, int* dp, in
     if (m) *m = f->m;
     if (dp) *dp = f->dp;
     if (mp) *mp = f->mp;
+    return 0;
+}
+
+int pnmol_filter_sweep_layout(const pnmol_filter* f, int* kernel, int* xcd_home) {
+    if (!f) return -1;
+    if (kernel) *kernel = f->sweep_mode == 0 ? 0 : (sweep_rl_enabled() && f->CB <= 17 ? 2 : 1);
+    if (xcd_home) *xcd_home = f->xcd_home;
     return 0;
 }
 
@@ -3708,6 +3743,7 @@ int pnmol_state_create(pnmol_filter* f, pnmol_state** out) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     pnmol_state* s = new pnmol_state();
     s->f = f;
+    f->states.fetch_add(1);
     const size_t Dp = (size_t)f->Dp;
     if (hipMalloc(&s->mean, sizeof(double) * Dp) != hipSuccess || hipMalloc(&s->var, sizeof(double) * Dp) != hipSuccess ||
         hipMalloc(&s->P, f->psz * Dp * Dp) != hipSuccess) {
@@ -3724,6 +3760,11 @@ int pnmol_state_create(pnmol_filter* f, pnmol_state** out) {
 
 int pnmol_state_destroy(pnmol_state* s) {
     if (!s) return -1;
+    if (s->f->pending_state == s) {
+        s->f->ctx->err = "pnmol_state_destroy: this state is the target of an unfinished pnmol_filter_steps_begin";
+        return -1;
+    }
+    s->f->states.fetch_sub(1);
     hipSetDevice(s->f->ctx->device);
     if (s->mean) hipFree(s->mean);
     if (s->var) hipFree(s->var);

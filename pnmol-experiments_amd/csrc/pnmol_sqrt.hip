@@ -1106,6 +1106,7 @@ extern "C" {
 
 int pnmol_sqrt_filter_destroy(pnmol_sqrt_filter* f) {
     if (!f) return -1;
+    f->ctx->children.fetch_sub(1);  // (lifetime rule, include/pnmol_hip.h: pnmol_ctx_destroy refuses while filters live)
     hipSetDevice(f->ctx->device);
     for (double* p : {f->Hraw, f->shift, f->EtT, f->QlT, f->mean, f->Cl, f->T1, f->mp, f->z, f->y, f->x, f->norms,
                       f->sqdiag, f->yq, f->xq, f->normsq, f->Rc})
@@ -1131,6 +1132,10 @@ int pnmol_sqrt_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmo
         ctx->err = "pnmol_sqrt_filter_create: d_state must be 0, d (white-noise model) or 2d (latent-force model)";
         return -1;
     }
+    if (desc->dtype != 0) {  // (the square-root form has no fp32 build: refuse rather than silently run fp64)
+        ctx->err = "pnmol_sqrt_filter_create: dtype must be 0 (fp64)";
+        return -1;
+    }
     QCHECK(ctx, hipSetDevice(ctx->device));
     if (int rc = qr_configure(ctx)) return rc;
     const int m = d + nB, D = n * ds;
@@ -1139,6 +1144,7 @@ int pnmol_sqrt_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmo
         return -1;
     }
     pnmol_sqrt_filter* f = new pnmol_sqrt_filter();
+    ctx->children.fetch_add(1);
     f->ctx = ctx, f->d = d, f->ds = ds, f->n = n, f->nu = nu, f->nB = nB, f->m = m, f->D = D;
     if (nB) f->hB.assign(desc->B, desc->B + (size_t)nB * ds);
     double Q1[SQN * SQN] = {0}, Lq[SQN * SQN] = {0};

@@ -4,7 +4,6 @@ There is no CPU fallback: if the library or a GPU is missing, the solver classes
 """
 
 import ctypes
-import weakref
 import os
 import pathlib
 
@@ -79,6 +78,7 @@ SYMBOLS = {
     "pnmol_filter_prepare_error_model": (ctypes.c_int, [_vp, ctypes.c_double]),
     "pnmol_filter_debug_read": (ctypes.c_int, [_vp, ctypes.c_int, _c_double_p, ctypes.c_long]),
     "pnmol_filter_dims": (ctypes.c_int, [_vp] + [ctypes.POINTER(ctypes.c_int)] * 5),
+    "pnmol_filter_sweep_layout": (ctypes.c_int, [_vp] + [ctypes.POINTER(ctypes.c_int)] * 2),
     # include/pnmol_sqrt.h
     "pnmol_qr_r": (ctypes.c_int, [_vp, _c_double_p, ctypes.c_int, ctypes.c_int, _c_double_p]),
     "pnmol_qr_last_ms": (ctypes.c_int, [ctypes.POINTER(ctypes.c_float)]),
@@ -234,16 +234,28 @@ class Filter:
         self.handle = h
         self.d, self.n, self.nB, self.m = d, int(num_derivatives) + 1, nB, d + nB
         self.error_model_dt = None
-        self._states = weakref.WeakSet()   # live `State`s: a pnmol_state must be destroyed before its pnmol_filter
+        # raw handles of the live pnmol_state objects of this filter, keyed by id(State): the C ABI refuses to destroy a
+        # filter that still has states (include/pnmol_hip.h, "Lifetimes").  A plain dict, not weak references: the
+        # cyclic collector clears weakrefs to unreachable objects BEFORE it runs finalisers, so a WeakSet would be empty
+        # exactly when a filter and its states die together -- and the states' device buffers would leak.
+        self._live = {}
 
     def __del__(self):
         # The cyclic garbage collector (and interpreter shutdown) finalises a filter and its states in ANY order: the
-        # states go first here, and a state whose filter is already gone does not touch the library (State.__del__).
-        for st in list(getattr(self, "_states", ())):
-            st._destroy()
+        # states' handles go first here; a State finalised later finds its entry gone and does nothing (State._destroy).
+        live = getattr(self, "_live", None)
+        while live:
+            _, sh = live.popitem()
+            self.lib.pnmol_state_destroy(sh)
         h, self.handle = getattr(self, "handle", None), None
         if h:
             self.lib.pnmol_filter_destroy(h)
+
+    def sweep_layout(self):
+        """(kernel, xcd_home) of this filter's sweep launch: `pnmol_filter_sweep_layout`."""
+        k, x = ctypes.c_int(0), ctypes.c_int(0)
+        self.lib.pnmol_filter_sweep_layout(self.handle, ctypes.byref(k), ctypes.byref(x))
+        return {"kernel": ("per_panel", "k_sweep", "k_sweep_rl")[k.value], "xcd_home": x.value}
 
     def dims(self):
         v = [ctypes.c_int(0) for _ in range(5)]
@@ -335,11 +347,13 @@ class State:
             _handle = _vp()
             self.ctx.check(self.lib.pnmol_state_create(flt.handle, ctypes.byref(_handle)), "pnmol_state_create")
         self.handle = _handle
-        flt._states.add(self)
+        flt._live[id(self)] = _handle
 
     def _destroy(self):
         h, self.handle = getattr(self, "handle", None), None
-        if h and getattr(self.filter, "handle", None):
+        flt = getattr(self, "filter", None)
+        # (no entry: Filter.__del__ ran first and has destroyed this state's handle already)
+        if h and flt is not None and flt._live.pop(id(self), None) is not None:
             self.lib.pnmol_state_destroy(h)
 
     def __del__(self):
