@@ -246,7 +246,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    # PNMOL_BENCH_FORCE_DIST=1: initialise the process group and run every collective of the N>1 path with ONE rank
+    # (no short-circuit): proves on a one-GPU box that RCCL loads beside libpnmol_hip.so's own HIP context and that
+    # device tensors round-trip through all_gather / all_reduce (profiles/r03_nccl_world1.log).
+    force_dist = os.environ.get("PNMOL_BENCH_FORCE_DIST", "0") == "1"
+    if force_dist and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_dist:
         import torch
         import torch.distributed as dist
         ndev = max(torch.cuda.device_count(), 1)
@@ -303,7 +312,7 @@ def main():
         sync_all()
         wall = time.perf_counter() - t0
         if dist is not None:
-            wall = batch.max_over_ranks(wall, dist, device=coll_dev)
+            wall = batch.max_over_ranks(wall, dist, device=coll_dev, force=force_dist)
         walls.append(wall)
         devs.append(max(p[1].last_steps_ms() for p in probs))  # HIP events on each problem's stream
     order = np.argsort(walls)
@@ -319,10 +328,10 @@ def main():
     kappa_by_rank = [kappas]
     if dist is not None:
         # the final gather of the per-problem read-outs -- the only collective of the path (RCCL over xGMI)
-        gathered = batch.gather_readouts(np.concatenate([means.ravel(), stds.ravel(), sig]), dist, device=coll_dev)
+        gathered = batch.gather_readouts(np.concatenate([means.ravel(), stds.ravel(), sig]), dist, device=coll_dev, force=force_dist)
         assert gathered.shape[0] == world, f"gathered read-outs of {gathered.shape[0]} ranks, world is {world}"
-        kappa_by_rank = batch.gather_readouts(np.array(kappas), dist, device=coll_dev).tolist()
-        ok = bool(batch.max_over_ranks(0.0 if ok else 1.0, dist, device=coll_dev) == 0.0) and bool(np.all(np.isfinite(gathered)))
+        kappa_by_rank = batch.gather_readouts(np.array(kappas), dist, device=coll_dev, force=force_dist).tolist()
+        ok = bool(batch.max_over_ranks(0.0 if ok else 1.0, dist, device=coll_dev, force=force_dist) == 0.0) and bool(np.all(np.isfinite(gathered)))
 
     if rank == 0:
         n, d = NU + 1, MESH_N
@@ -349,7 +358,10 @@ def main():
             "config": {"workload": f"1-D heat equation, N={MESH_N} mesh, IWP(nu={NU}) EK1, Dirichlet, dt=2^-7, "
                                    f"one problem per GPU (kappa sweep), D={D}, m={m}",
                        "steps_in_one_call": args.steps, "valid": ok, "problems_per_gpu": B,
-                       "device_ms_per_step": step_ms_dev, "kappa_by_rank": kappa_by_rank},
+                       "device_ms_per_step": step_ms_dev, "kappa_by_rank": kappa_by_rank,
+                       "sweep_layout": probs[0][1].sweep_layout(),
+                       "collectives": ("%s, one rank, forced" % os.environ.get("PNMOL_BENCH_BACKEND", "nccl")) if (force_dist and world == 1)
+                                      else (os.environ.get("PNMOL_BENCH_BACKEND", "nccl") if world > 1 else None)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "note": "unit = one filter step (the kernel graph of one predict+update): F_alg = %.4g "

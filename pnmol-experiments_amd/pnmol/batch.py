@@ -22,10 +22,12 @@ def shard(num_problems, rank, world_size):
     return list(range(rank, num_problems, world_size))
 
 
-def gather_readouts(payload, dist=None, device="cpu"):
-    """All-gather equally shaped float64 arrays: returns an array (world_size, *payload.shape)."""
+def gather_readouts(payload, dist=None, device="cpu", force=False):
+    """All-gather equally shaped float64 arrays: returns an array (world_size, *payload.shape).
+
+    A one-rank group skips the collective unless `force` (used to exercise the RCCL path on a one-GPU box)."""
     payload = np.ascontiguousarray(payload, dtype=np.float64)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return payload[None]
     import torch
 
@@ -35,8 +37,8 @@ def gather_readouts(payload, dist=None, device="cpu"):
     return np.stack([o.cpu().numpy() for o in out])
 
 
-def max_over_ranks(value, dist=None, device="cpu"):
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+def max_over_ranks(value, dist=None, device="cpu", force=False):
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return float(value)
     import torch
 
