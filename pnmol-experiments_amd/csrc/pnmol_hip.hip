@@ -774,6 +774,67 @@ __device__ __forceinline__ void front_block(const PT* __restrict__ Ppred, double
     if (i < mp) G[((long)mp + Dp + NB + q) * mp + i] = (q == i) ? 1.0 : 0.0;
 }
 
+// The same rows of G by FEW, FAT workgroups (the constant-step loop's k_readout launch, where this gather is serial with the
+// sweep): front_block's one-row blocks need (mp/256 rounded up) x (Dp + mp) = 6240 workgroups at N = 512 -- three rounds of
+// resident blocks, each a chain of dependent loads (stencil row, then the gather) with one entry per thread: 12.7 us.  Here
+//   blocks [0, Dp/8)                 8 rows of P- H^T: a thread keeps the stencil rows of ITS columns (i = tid, tid+256, ..)
+//                                    and runs them over the 8 rows with all gathers of a row group in flight,
+//   blocks [Dp/8, Dp/8 + CB(CB+1)/2) one block-lower 32x32 tile of S: four entries per thread.
+// Same device functions, same association order: the entries are bit-identical to front_block's.
+__host__ __device__ inline int front_tiled_blocks(long Dp, int mp) { return (int)(Dp / 8) + (mp / NB) * (mp / NB + 1) / 2; }
+template <typename PT>
+__device__ __forceinline__ void front_block_tiled(const PT* __restrict__ Ppred, double* __restrict__ G,
+                                                  const double* __restrict__ rdiag, const double* __restrict__ Rdense,
+                                                  const MeasModel& mm, long Dp, int fb) {
+    const int tid = threadIdx.x, mp = mm.mp;
+    const bool narrow = mm.w <= HW;
+    const int nP = (int)(Dp / 8);
+    if (fb < nP) {
+        const long y0 = (long)fb * 8;
+        for (int i = tid; i < mp; i += 256) {
+            if (i >= mm.m) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) G[((long)mp + y0 + q) * mp + i] = 0.0;
+                continue;
+            }
+            double v[8];
+            if (narrow) {
+                HRow rc;
+                h_row_load(mm, i, rc);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = h_row_dot_w<HW>(rc, Ppred + (y0 + q) * Dp);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = h_row_dot(mm, i, Ppred + (y0 + q) * Dp);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) G[((long)mp + y0 + q) * mp + i] = v[q];
+        }
+        return;
+    }
+    int t = fb - nP;  // lower tile (I, J), t = I (I + 1) / 2 + J
+    int I = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((I + 1) * (I + 2) / 2 <= t) ++I;
+    while (I * (I + 1) / 2 > t) --I;
+    const int J = t - I * (I + 1) / 2;
+    const int i = J * NB + (tid & 31);
+    HRow rc;
+    if (narrow && i < mm.m) h_row_load(mm, i, rc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ip = I * NB + (tid >> 5) + 8 * q;
+        double v;
+        if (narrow && ip < mm.m && i < mm.m) {
+            HRow rr;
+            h_row_load(mm, ip, rr);
+            v = s_entry_w<HW>(Ppred, Dp, mm, rr, rc, ip, i, rdiag, Rdense);
+        } else {
+            v = s_entry(Ppred, Dp, mm, ip, i, rdiag, Rdense);
+        }
+        G[(long)ip * mp + i] = v;
+    }
+}
+
 // the identity block of G never changes (k_sweep only reads G): written once, at filter creation
 __global__ void k_set_identity(double* __restrict__ Gi, int mp) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2868,9 +2929,9 @@ __global__ __launch_bounds__(256) void k_readout(const double* __restrict__ mean
         // blocks behind the read-out and role blocks: the NEXT step's k_front (G from the P- the down-date epilogue
         // has just written) -- independent of the rest of this launch, which hides behind it
         if ((int)blockIdx.x > rblocks) {
-            const int fb = blockIdx.x - rblocks - 1, gx = (mp + 255) / 256;
-            if (p32) front_block(static_cast<const float*>(Ppred), ra.G, rdiag, Rdense, ra.mm, (long)N * ra.dp, fb % gx, fb / gx);
-            else front_block(static_cast<const double*>(Ppred), ra.G, rdiag, Rdense, ra.mm, (long)N * ra.dp, fb % gx, fb / gx);
+            const int fb = blockIdx.x - rblocks - 1;
+            if (p32) front_block_tiled(static_cast<const float*>(Ppred), ra.G, rdiag, Rdense, ra.mm, (long)N * ra.dp, fb);
+            else front_block_tiled(static_cast<const double*>(Ppred), ra.G, rdiag, Rdense, ra.mm, (long)N * ra.dp, fb);
             return;
         }
     }
@@ -3147,8 +3208,8 @@ int launch_step(pnmol_filter* f, const double* Pin, const double* min, double fr
                                                     record ? f->rec_stds : nullptr, nordsieck_scale(f->nu, 0, dt), f->d,
                                                     f->part, f->rec, mp, f->ctr, ra, f->tickets, (int)rblocks, f->Ppred, f->rdiag,
                                                     f->Rdense, f->p32);
-    else  // + the next step's vector predict (1 block) and k_front ((mp/256 rounded up) x (Dp + mp) blocks)
-        k_readout<N, true><<<rblocks + 1 + (unsigned)(((mp + 255) / 256) * (Dp + mp)), 256, sizeof(double) * Dp, st>>>(
+    else  // + the next step's vector predict (1 block) and the next G (front_block_tiled: Dp/8 + CB(CB+1)/2 blocks)
+        k_readout<N, true><<<rblocks + 1 + (unsigned)front_tiled_blocks(Dp, mp), 256, sizeof(double) * Dp, st>>>(
             mout, varout, record ? f->rec_means : nullptr, record ? f->rec_stds : nullptr, nordsieck_scale(f->nu, 0, dt),
             f->d, f->part, f->rec, mp, f->ctr, ra, f->tickets, (int)rblocks, f->Ppred, f->rdiag, f->Rdense, f->p32);
     hipError_t e = hipGetLastError();
@@ -3645,12 +3706,14 @@ int pnmol_filter_prepare_error_model(pnmol_filter* f, double dt) {
     hipStream_t st = ctx->stream;
     const int mp = f->mp, m = f->m, dp = f->dp;
     const long Dp = f->Dp;
-    if (!f->Qfull) {
-        HIPCHK(ctx, hipMalloc(&f->Qfull, f->psz * (size_t)Dp * Dp));
+    if (!f->one) {  // (pnmol_state_get_cov_sqrtm may have made them already: found by the sanitizer run, tests/asan)
         HIPCHK(ctx, hipMalloc(&f->one, sizeof(int)));
         HIPCHK(ctx, hipMalloc(&f->info_err, sizeof(int)));
         const int h1 = 1;
         HIPCHK(ctx, hipMemcpy(f->one, &h1, sizeof(int), hipMemcpyHostToDevice));
+    }
+    if (!f->Qfull) {
+        HIPCHK(ctx, hipMalloc(&f->Qfull, f->psz * (size_t)Dp * Dp));
         k_fill_q<<<(unsigned)((Dp * Dp + 255) / 256), 256, 0, st>>>(f->Qfull, f->Kg, f->iwp, f->n, dp, f->p32);
     }
     const bool fresh = (f->Sqinv == nullptr);
