@@ -74,6 +74,10 @@ typedef struct pnmol_filter_desc {
                               sweep (Ls, W, r), the mean and every scalar stay fp64.  Buffers crossing this boundary are
                               double either way.  Needs num_derivatives <= 2.  What it costs in accuracy: DESIGN.md
                               section 11 (tolerance study). */
+    const double* K;       /* optional (d_state,d_state): the Gram matrix Gamma Gamma^T = spatial_kernel(X, X^T) of white.py:84-85
+                              (base/iwp.py:49-52 uses it as Ql Ql^T = Q1 (x) K).  NULL: the library forms Gamma Gamma^T itself,
+                              an O(d^3) scalar loop on the host (seconds at d = 4096); a caller that has the Gram matrix anyway
+                              passes it.  Ignored by pnmol_sqrt_filter_create (the QR form works on Gamma itself). */
 } pnmol_filter_desc;
 
 int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_filter** out);

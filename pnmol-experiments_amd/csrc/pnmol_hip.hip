@@ -3548,6 +3548,10 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
     }
     // K = Gamma Gamma^T (white.py:84-85, base/iwp.py:49-52), padded
     std::vector<double> Kg((size_t)dp * dp, 0.0);
+    if (desc->K) {  // the caller's Gram matrix (symmetrised: both triangles from its lower one, like the loop below)
+        for (int i = 0; i < ds; ++i)
+            for (int k = 0; k <= i; ++k) Kg[(size_t)i * dp + k] = Kg[(size_t)k * dp + i] = desc->K[(size_t)i * ds + k];
+    } else
     for (int i = 0; i < ds; ++i)
         for (int k = 0; k <= i; ++k) {
             double s = 0.0;

@@ -41,6 +41,7 @@ class FilterDesc(ctypes.Structure):
         ("Gamma", _c_double_p),
         ("d_state", ctypes.c_int),
         ("dtype", ctypes.c_int),      # 0 fp64, 1 fp32 covariance (include/pnmol_hip.h)
+        ("K", _c_double_p),           # optional Gram matrix Gamma Gamma^T (saves the library an O(d^3) host loop)
     ]
 
 
@@ -218,7 +219,7 @@ class Filter:
 
     DTYPES = {"f64": 0, "f32": 1}
 
-    def __init__(self, ctx, *, L, B, E_sqrtm, R_sqrtm, Gamma, num_derivatives, dtype="f64"):
+    def __init__(self, ctx, *, L, B, E_sqrtm, R_sqrtm, Gamma, num_derivatives, dtype="f64", K=None):
         """dtype "f32": the covariance and its bulk kernels (predict, H-apply, down-date) in fp32; the factorisation of
         the innovation matrix, the mean and all scalars stay fp64 (`pnmol_filter_desc.dtype`)."""
         self.ctx, self.lib = ctx, ctx.lib
@@ -226,7 +227,8 @@ class Filter:
         nB = B.shape[0]
         self._keep = [_f64(L, (d, ds)), _f64(B, (nB, ds)), _f64(E_sqrtm, (d, d)), _f64(R_sqrtm, (nB, nB)),
                       _f64(Gamma, (ds, ds))]
-        desc = FilterDesc(d, int(num_derivatives), nB, *[_dp(a) for a in self._keep], ds, self.DTYPES[dtype])
+        gram = _f64(self._keep[4] @ self._keep[4].T if K is None else K, (ds, ds))   # (BLAS here; a scalar loop in the library)
+        desc = FilterDesc(d, int(num_derivatives), nB, *[_dp(a) for a in self._keep], ds, self.DTYPES[dtype], _dp(gram))
         self.dtype = dtype
         self.ds = ds
         h = _vp()
