@@ -210,6 +210,29 @@ def secondary_points(device):
                     "frac_of_fp64_mfma_peak": f_alg(D, mm, nn) / (ms * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS})
     except Exception as e:
         out.append({"workload": "2-D heat 64x64 mesh nu=1 (fp64)", "error": repr(e)[:200]})
+    try:
+        # semilinear EK1 (white.py:189-208) on the reference's spruce-budworm recipe: one attempt_step per call -- predicted
+        # mean to the host, f / df there (Python callables, as in the reference), new stencil rows to the device, step
+        import pnmol
+        dts, K, Ns = 2.0 ** -7, 20, 256
+        spde = pnmol.pde.examples.spruce_budworm_1d_discretized(dx=1.0 / (Ns - 1), tmax=(K + 4) * dts, diffusion_rate=0.05,
+                                                                kernel=pnmol.kernels.SquareExponential())
+        row = {"workload": f"spruce budworm N={Ns} nu={NU}, SemiLinearWhiteNoiseEK1.attempt_step (host wall clock per step)"}
+        for key, diagonal in (("ms_per_step", True), ("ms_per_step_dense_operator_upload", False)):
+            ssolver = pnmol.white.SemiLinearWhiteNoiseEK1(num_derivatives=NU, steprule=pnmol.odetools.step.Constant(dts),
+                                                          spatial_kernel=pnmol.kernels.Matern52() + pnmol.kernels.WhiteNoise())
+            if not diagonal:
+                spde.df_diagonal = None
+            st = ssolver.initialize(spde)
+            for _ in range(3):
+                st, _ = ssolver.attempt_step(st, dts, spde)
+            t0 = time.perf_counter()
+            for _ in range(K):
+                st, _ = ssolver.attempt_step(st, dts, spde)
+            row[key] = 1e3 * (time.perf_counter() - t0) / K
+        out.append(row)
+    except Exception as e:
+        out.append({"workload": "spruce budworm semilinear step", "error": repr(e)[:200]})
     return out
 
 

@@ -47,6 +47,17 @@ int pnmol_ctx_destroy(pnmol_ctx* ctx); /* -1, nothing freed, while filters of ct
 int pnmol_ctx_synchronize(pnmol_ctx* ctx);
 const char* pnmol_last_error(pnmol_ctx* ctx);
 
+/* cold-path assembly on the device ----------------------------------------------------------
+ * Batched kernel finite-difference stencils, `discretize.fd_coefficients` under `jax.vmap` (discretize.py:60,75-80,177-201):
+ * for every mesh point p,  weights_p = (gram_p)^-1 lk_p  (gram_p = k(X_p, X_p) + nugget I, (s,s); lk_p = L k(x_p, X_p), (s)),
+ * uncertainty_p = llk_p - weights_p . lk_p  (llk_p = L L k(x_p, x_p)).  1 <= s <= 16.  LU with partial pivoting per point. */
+int pnmol_fd_solve_batched(pnmol_ctx* ctx, const double* gram_nss, const double* lk_ns, const double* llk_n, int N, int s,
+                           double* weights_ns, double* uncertainty_n);
+/* Gamma = chol(K): `jnp.linalg.cholesky(spatial_kernel(X, X.T))` (white.py:84-85, latent.py:139) with the step's own sweep
+ * kernels.  A (n,n) symmetric positive definite, row-major; L (n,n) lower triangular (upper part zeroed).
+ * -3: not positive definite (the failing pivot is in `pnmol_last_error`). */
+int pnmol_cholesky_lower(pnmol_ctx* ctx, const double* A_nn, int n, double* L_nn);
+
 /* problem description = the attributes `attempt_step` reads from `pde`
  * (white.py:96-146, :169-186; pde/mixins.py:19-59) and from the solver
  * (`num_derivatives`, pdefilter.py:37-70; Gamma = chol(spatial_kernel(X, X.T)),
@@ -108,6 +119,11 @@ int pnmol_filter_prepare_error_model(pnmol_filter* f, double dt);
  * `pnmol_filter_step(s)` calls.  The boundary rows B are kept. */
 int pnmol_filter_predict_mean(pnmol_filter* f, const pnmol_state* in, double dt, double* m_at_d);
 int pnmol_filter_set_operator(pnmol_filter* f, const double* M_dds, const double* shift_d);
+/* The same for a POINTWISE nonlinearity, whose Jacobian is diagonal (`df_diagonal` of the reference's problem classes,
+ * pde/problems.py; spruce budworm: pde/examples.py:292-341): M = L + diag(jdiag) with the L given at creation.  d + d numbers
+ * cross the bus instead of a dense (d, d_state) matrix, the stencil rows are patched on the device (no host scan of M, no
+ * stream synchronisation, captured graphs stay valid).  -1 if a row of L has no diagonal entry. */
+int pnmol_filter_set_operator_diagonal(pnmol_filter* f, const double* jdiag_d, const double* shift_d);
 
 /* states ----------------------------------------------------------------------------- */
 int pnmol_state_create(pnmol_filter* f, pnmol_state** out);

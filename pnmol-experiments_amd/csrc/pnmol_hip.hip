@@ -2981,6 +2981,69 @@ __global__ __launch_bounds__(256) void k_readout(const double* __restrict__ mean
     }
 }
 
+// M = L + diag(j) on the device (semilinear EK1 with a pointwise nonlinearity, white.py:192-208: J_x = diag(df/du)): the
+// ELL image of Hv = [-M; B] is the base image with -j_i added to the diagonal entry of PDE row i; the shift comes along.
+__global__ void k_operator_diagonal(double* __restrict__ ell_val, const double* __restrict__ base_val,
+                                    const int* __restrict__ slot, const double* __restrict__ op /* [jdiag d | shift mp] */,
+                                    double* __restrict__ shift, int d, int mp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= mp) return;
+    if (i < d) {
+        const int e = slot[i];
+        ell_val[(long)e * mp + i] = base_val[(long)e * mp + i] - op[i];
+    }
+    shift[i] = op[d + i];
+}
+
+// Batched kernel finite-difference stencils (discretize.py:177-201): per mesh point p an s x s system
+//     w_p = (k(X_p, X_p) + eta I)^-1 Lk(x_p, X_p),     u_p = LLk(x_p, x_p) - w_p . Lk(x_p, X_p)
+// (X_p = the s stencil neighbours; the reference vmaps jnp.linalg.solve over the points).  One thread per point: LU with
+// partial pivoting in registers, like LAPACK's getf2 on the s x s matrix (same pivot rule, same update order).
+constexpr int FD_MAXS = 16;
+__global__ __launch_bounds__(128) void k_fd_solve(const double* __restrict__ gram, const double* __restrict__ dk,
+                                                  const double* __restrict__ llk, int N, int s, double* __restrict__ w,
+                                                  double* __restrict__ unc) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    double A[FD_MAXS][FD_MAXS], b[FD_MAXS];
+    for (int i = 0; i < s; ++i) {
+        for (int k = 0; k < s; ++k) A[i][k] = gram[((long)p * s + i) * s + k];
+        b[i] = dk[(long)p * s + i];
+    }
+    for (int c = 0; c < s; ++c) {
+        int piv = c;
+        double best = fabs(A[c][c]);
+        for (int i = c + 1; i < s; ++i)
+            if (fabs(A[i][c]) > best) best = fabs(A[i][c]), piv = i;
+        if (piv != c) {
+            for (int k = 0; k < s; ++k) {
+                const double t = A[c][k];
+                A[c][k] = A[piv][k], A[piv][k] = t;
+            }
+            const double t = b[c];
+            b[c] = b[piv], b[piv] = t;
+        }
+        const double inv = 1.0 / A[c][c];
+        for (int i = c + 1; i < s; ++i) {
+            const double f = A[i][c] * inv;
+            A[i][c] = f;
+            for (int k = c + 1; k < s; ++k) A[i][k] -= f * A[c][k];
+        }
+    }
+    for (int i = 1; i < s; ++i)          // L y = P b
+        for (int k = 0; k < i; ++k) b[i] -= A[i][k] * b[k];
+    for (int i = s - 1; i >= 0; --i) {   // U x = y
+        for (int k = i + 1; k < s; ++k) b[i] -= A[i][k] * b[k];
+        b[i] /= A[i][i];
+    }
+    double dot = 0.0;
+    for (int i = 0; i < s; ++i) {
+        w[(long)p * s + i] = b[i];
+        dot += b[i] * dk[(long)p * s + i];
+    }
+    unc[p] = llk[p] - dot;
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -3027,6 +3090,15 @@ struct pnmol_filter {
     IwpConsts iwp{};
     int* ell_col = nullptr;
     double* ell_val = nullptr;
+    // the operator given at creation (pde.L), kept for pnmol_filter_set_operator_diagonal: its ELL image, the slot of the
+    // diagonal entry of every PDE row (-1: the row has none), and a pinned staging buffer [jdiag d | shift mp]
+    int* ell_col_base = nullptr;
+    double* ell_val_base = nullptr;
+    int* ell_diag_slot = nullptr;
+    int base_w = 0, base_has_diag = 0;
+    double* h_op = nullptr;
+    double* h_op_dev = nullptr;
+    hipEvent_t ev_op = nullptr;
     double *Kg = nullptr, *rdiag = nullptr, *Rdense = nullptr, *shift = nullptr;
     double *G = nullptr, *F = nullptr, *Linv = nullptr, *Ppred = nullptr, *mpred = nullptr, *zbuf = nullptr;
     double *var = nullptr, *Sqinv = nullptr, *rec = nullptr, *part = nullptr, *sdiag = nullptr;
@@ -3466,6 +3538,92 @@ int pnmol_ctx_synchronize(pnmol_ctx* ctx) {
 
 const char* pnmol_last_error(pnmol_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 
+int pnmol_fd_solve_batched(pnmol_ctx* ctx, const double* gram_nss, const double* lk_ns, const double* llk_n, int N, int s,
+                           double* weights_ns, double* uncertainty_n) {
+    if (!ctx || !gram_nss || !lk_ns || !llk_n || !weights_ns || !uncertainty_n || N < 1 || s < 1 || s > FD_MAXS) {
+        if (ctx) ctx->err = "pnmol_fd_solve_batched: bad argument (need N >= 1, 1 <= s <= 16, non-null buffers)";
+        return -1;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    double* d = nullptr;
+    const size_t nG = (size_t)N * s * s, nV = (size_t)N * s;
+    HIPCHK(ctx, hipMalloc(&d, sizeof(double) * (nG + 2 * nV + 2 * (size_t)N)));
+    double *dG = d, *dK = dG + nG, *dL = dK + nV, *dW = dL + N, *dU = dW + nV;
+    hipError_t e = hipMemcpyAsync(dG, gram_nss, sizeof(double) * nG, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(dK, lk_ns, sizeof(double) * nV, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(dL, llk_n, sizeof(double) * N, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        k_fd_solve<<<(unsigned)((N + 127) / 128), 128, 0, st>>>(dG, dK, dL, N, s, dW, dU);
+        e = hipMemcpyAsync(weights_ns, dW, sizeof(double) * nV, hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(uncertainty_n, dU, sizeof(double) * N, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipGetLastError();
+    (void)hipFree(d);
+    if (e != hipSuccess) {
+        ctx->err = std::string("pnmol_fd_solve_batched: ") + hipGetErrorString(e);
+        return -2;
+    }
+    return 0;
+}
+
+int pnmol_cholesky_lower(pnmol_ctx* ctx, const double* A_nn, int n, double* L_nn) {
+    if (!ctx || !A_nn || !L_nn || n < 1) return -1;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int Dq = round_up(n, NB), cb = Dq / NB;
+    const size_t nflags = (size_t)std::max(2 * cb + 1 + cb * cb, rl_flags(cb, cb).total);
+    const size_t ntile = (size_t)std::max(cb * cb, 2 * cb + 2);
+    double *Gc = nullptr, *Fc = nullptr, *Lc = nullptr, *hs = nullptr;
+    int* iw = nullptr;  // [flags | info | one]
+    std::vector<double> hG((size_t)Dq * Dq, 0.0);
+    for (int i = 0; i < n; ++i) std::memcpy(&hG[(size_t)i * Dq], A_nn + (size_t)i * n, sizeof(double) * n);
+    for (int i = n; i < Dq; ++i) hG[(size_t)i * Dq + i] = 1.0;
+    hipError_t e = hipMalloc(&Gc, sizeof(double) * hG.size());
+    if (e == hipSuccess) e = hipMalloc(&Fc, sizeof(double) * hG.size());
+    if (e == hipSuccess) e = hipMalloc(&Lc, sizeof(double) * (size_t)cb * NB * NB);
+    if (e == hipSuccess) e = hipMalloc(&hs, sizeof(double) * ntile * NB * NB);
+    if (e == hipSuccess) e = hipMalloc(&iw, sizeof(int) * (nflags + 2));
+    int inf = 0;
+    if (e == hipSuccess) {
+        const int init[2] = {0x7f7f7f7f, 1};
+        e = hipMemcpyAsync(Gc, hG.data(), sizeof(double) * hG.size(), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemsetAsync(Fc, 0, sizeof(double) * hG.size(), st);
+        if (e == hipSuccess) e = hipMemsetAsync(Lc, 0, sizeof(double) * (size_t)cb * NB * NB, st);
+        if (e == hipSuccess) e = hipMemsetAsync(iw, 0, sizeof(int) * nflags, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(iw + nflags, init, sizeof(init), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) {
+            DowndateArgs dd{};
+            // (strict pivots: a Gram matrix that is not numerically positive definite is an error, as in LAPACK's potrf)
+            launch_sweep<2, false>((unsigned)cb, st, Gc, Fc, Lc, Dq, cb, cb, iw, iw + nflags, iw + nflags + 1, dd, iw + 2 * cb + 1, hs, 0, -1);
+            e = hipMemcpyAsync(hG.data(), Fc, sizeof(double) * hG.size(), hipMemcpyDeviceToHost, st);
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(&inf, iw + nflags, sizeof(int), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = hipGetLastError();
+    }
+    for (void* q : {(void*)Gc, (void*)Fc, (void*)Lc, (void*)hs, (void*)iw})
+        if (q) (void)hipFree(q);
+    if (e != hipSuccess) {
+        ctx->err = std::string("pnmol_cholesky_lower: ") + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? -4 : -2;
+    }
+    if (inf == -2) {
+        ctx->err = "pnmol_cholesky_lower: a dependency wait timed out";
+        return -2;
+    }
+    if (inf < Dq) {
+        ctx->err = "pnmol_cholesky_lower: matrix not positive definite at pivot " + std::to_string(inf);
+        return -3;
+    }
+    for (int i = 0; i < n; ++i) {
+        std::memcpy(L_nn + (size_t)i * n, &hG[(size_t)i * Dq], sizeof(double) * (i + 1));
+        for (int k = i + 1; k < n; ++k) L_nn[(size_t)i * n + k] = 0.0;
+    }
+    return 0;
+}
+
 int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_filter** out) {
     if (!ctx || !desc || !out) return -1;
     *out = nullptr;
@@ -3625,6 +3783,26 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
     }
     FCHK(hipMemcpy(f->ell_col, ecol.data(), sizeof(int) * ecol.size(), hipMemcpyHostToDevice));
     FCHK(hipMemcpy(f->ell_val, eval.data(), sizeof(double) * eval.size(), hipMemcpyHostToDevice));
+    {   // base operator for pnmol_filter_set_operator_diagonal
+        std::vector<int> slot((size_t)mp, 0);
+        f->base_has_diag = 1;
+        for (int i = 0; i < d; ++i) {
+            int e = 0;
+            while (e < w && ecol[(size_t)e * mp + i] != i) ++e;
+            if (e == w) f->base_has_diag = 0, e = 0;
+            slot[i] = e;
+        }
+        f->base_w = w;
+        FCHK(hipMalloc(&f->ell_col_base, sizeof(int) * ecol.size()));
+        FCHK(hipMalloc(&f->ell_val_base, sizeof(double) * eval.size()));
+        FCHK(hipMalloc(&f->ell_diag_slot, sizeof(int) * mp));
+        FCHK(hipMemcpy(f->ell_col_base, ecol.data(), sizeof(int) * ecol.size(), hipMemcpyHostToDevice));
+        FCHK(hipMemcpy(f->ell_val_base, eval.data(), sizeof(double) * eval.size(), hipMemcpyHostToDevice));
+        FCHK(hipMemcpy(f->ell_diag_slot, slot.data(), sizeof(int) * mp, hipMemcpyHostToDevice));
+        FCHK(hipHostMalloc(&f->h_op, sizeof(double) * (size_t)(d + mp), hipHostMallocMapped));
+        FCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&f->h_op_dev), f->h_op, 0));
+        FCHK(hipEventCreate(&f->ev_op));
+    }
     FCHK(hipMemcpy(f->Kg, Kg.data(), sizeof(double) * Kg.size(), hipMemcpyHostToDevice));
     FCHK(hipMemcpy(f->rdiag, rdiag.data(), sizeof(double) * mp, hipMemcpyHostToDevice));
     if (!diag) {
@@ -3664,6 +3842,10 @@ int pnmol_filter_destroy(pnmol_filter* f) {
                     f->info,    f->tmpP,    f->tmpMean, f->rec_means, f->rec_stds, f->flags, f->Qfull, f->one, f->info_err, f->hs_scratch, f->last_ctr, f->tickets};
     for (void* p : ptrs)
         if (p) hipFree(p);
+    if (f->h_op) hipHostFree(f->h_op);
+    if (f->ev_op) hipEventDestroy(f->ev_op);
+    for (void* q : {(void*)f->ell_col_base, (void*)f->ell_val_base, (void*)f->ell_diag_slot})
+        if (q) hipFree(q);
     if (f->ev0) hipEventDestroy(f->ev0);
     if (f->ev1) hipEventDestroy(f->ev1);
     delete f;
@@ -3764,8 +3946,8 @@ int pnmol_filter_set_operator(pnmol_filter* f, const double* M_dd, const double*
     std::vector<int> ecol;
     std::vector<double> eval;
     const int w = build_ell(M_dd, f->hB.data(), f->d, f->ds, f->nB, f->mp, ecol, eval);
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    drop_graphs(f);  // the stencil width / pointers are baked into captured launches
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // (pageable host buffers: the copies below are synchronous anyway)
+    if (w != f->ellw || w > f->ell_cap) drop_graphs(f);  // the stencil width / pointers are baked into captured launches
     if (w > f->ell_cap) {
         if (f->ell_col) (void)hipFree(f->ell_col);
         if (f->ell_val) (void)hipFree(f->ell_val);
@@ -3780,6 +3962,33 @@ int pnmol_filter_set_operator(pnmol_filter* f, const double* M_dd, const double*
     std::vector<double> sh((size_t)f->mp, 0.0);
     if (shift_d) std::memcpy(sh.data(), shift_d, sizeof(double) * f->d);
     HIPCHK(ctx, hipMemcpy(f->shift, sh.data(), sizeof(double) * sh.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int pnmol_filter_set_operator_diagonal(pnmol_filter* f, const double* jdiag_d, const double* shift_d) {
+    if (!f || !jdiag_d) return -1;
+    pnmol_ctx* ctx = f->ctx;
+    if (!f->base_has_diag) {
+        ctx->err = "pnmol_filter_set_operator_diagonal: a row of the operator given at creation has no diagonal entry";
+        return -1;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    // the staging buffer may still be read by the previous call's kernel: wait for THAT kernel, not for the stream
+    HIPCHK(ctx, hipEventSynchronize(f->ev_op));
+    const int d = f->d, mp = f->mp;
+    std::memcpy(f->h_op, jdiag_d, sizeof(double) * d);
+    for (int i = 0; i < mp; ++i) f->h_op[d + i] = (shift_d && i < d) ? shift_d[i] : 0.0;
+    if (f->ellw != f->base_w) {  // a dense pnmol_filter_set_operator came in between: back to the base image
+        drop_graphs(f);
+        HIPCHK(ctx, hipMemcpyAsync(f->ell_col, f->ell_col_base, sizeof(int) * (size_t)f->base_w * mp, hipMemcpyDeviceToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(f->ell_val, f->ell_val_base, sizeof(double) * (size_t)f->base_w * mp, hipMemcpyDeviceToDevice, st));
+        f->ellw = f->base_w;
+    }
+    k_operator_diagonal<<<(unsigned)((mp + 255) / 256), 256, 0, st>>>(f->ell_val, f->ell_val_base, f->ell_diag_slot, f->h_op_dev,
+                                                                       f->shift, d, mp);
+    HIPCHK(ctx, hipEventRecord(f->ev_op, st));
+    HIPCHK(ctx, hipGetLastError());
     return 0;
 }
 

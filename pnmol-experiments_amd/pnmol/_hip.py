@@ -53,12 +53,16 @@ SYMBOLS = {
     "pnmol_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
     "pnmol_ctx_destroy": (ctypes.c_int, [_vp]),
     "pnmol_ctx_synchronize": (ctypes.c_int, [_vp]),
+    "pnmol_fd_solve_batched": (ctypes.c_int, [_vp, _c_double_p, _c_double_p, _c_double_p, ctypes.c_int, ctypes.c_int,
+                                              _c_double_p, _c_double_p]),
+    "pnmol_cholesky_lower": (ctypes.c_int, [_vp, _c_double_p, ctypes.c_int, _c_double_p]),
     "pnmol_last_error": (ctypes.c_char_p, [_vp]),
     "pnmol_filter_create": (ctypes.c_int, [_vp, ctypes.POINTER(FilterDesc), ctypes.POINTER(_vp)]),
     "pnmol_filter_destroy": (ctypes.c_int, [_vp]),
     "pnmol_filter_set_error_model": (ctypes.c_int, [_vp, ctypes.c_double, _c_double_p, _c_double_p]),
     "pnmol_filter_predict_mean": (ctypes.c_int, [_vp, _vp, ctypes.c_double, _c_double_p]),
     "pnmol_filter_set_operator": (ctypes.c_int, [_vp, _c_double_p, _c_double_p]),
+    "pnmol_filter_set_operator_diagonal": (ctypes.c_int, [_vp, _c_double_p, _c_double_p]),
     "pnmol_state_create": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
     "pnmol_state_destroy": (ctypes.c_int, [_vp]),
     "pnmol_state_clone": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
@@ -161,6 +165,28 @@ class Context:
         if device not in cls._cache:
             cls._cache[device] = cls(device)
         return cls._cache[device]
+
+    def cholesky(self, A):
+        """Lower Cholesky factor of a symmetric positive definite matrix on the device (`pnmol_cholesky_lower`):
+        `jnp.linalg.cholesky(spatial_kernel(X, X.T))`, white.py:84-85."""
+        A = _f64(A)
+        n = A.shape[0]
+        if A.shape != (n, n):
+            raise ValueError(f"expected a square matrix, got {A.shape}")
+        L = np.empty((n, n))
+        self.check(self.lib.pnmol_cholesky_lower(self.handle, _dp(A), n, _dp(L)), "pnmol_cholesky_lower")
+        return L
+
+    def fd_solve_batched(self, gram, lk, llk):
+        """weights (N, s), uncertainty (N,) of N kernel-FD stencils (`pnmol_fd_solve_batched`; discretize.py:177-201)."""
+        gram, lk, llk = _f64(gram), _f64(lk), _f64(llk)
+        N, s = lk.shape
+        if gram.shape != (N, s, s) or llk.shape != (N,):
+            raise ValueError(f"shapes {gram.shape}, {lk.shape}, {llk.shape} do not describe N stencils of size s")
+        w, u = np.empty((N, s)), np.empty(N)
+        self.check(self.lib.pnmol_fd_solve_batched(self.handle, _dp(gram), _dp(lk), _dp(llk), N, s, _dp(w), _dp(u)),
+                   "pnmol_fd_solve_batched")
+        return w, u
 
     def qr_r(self, A):
         """R factor (upper, diag >= 0) of A on the device: `jnp.linalg.qr(A, mode="r")` (base/sqrt.py:21)."""
@@ -289,6 +315,14 @@ class Filter:
         b = _f64(shift, (self.d,)) if shift is not None else None
         self.ctx.check(self.lib.pnmol_filter_set_operator(self.handle, _dp(a), _dp(b) if b is not None else None),
                        "pnmol_filter_set_operator")
+        self.error_model_dt = None
+
+    def set_operator_diagonal(self, jdiag, shift=None):
+        """M = L + diag(jdiag) (pointwise nonlinearity): `pnmol_filter_set_operator_diagonal`."""
+        a = _f64(jdiag, (self.d,))
+        b = _f64(shift, (self.d,)) if shift is not None else None
+        self.ctx.check(self.lib.pnmol_filter_set_operator_diagonal(self.handle, _dp(a), _dp(b) if b is not None else None),
+                       "pnmol_filter_set_operator_diagonal")
         self.error_model_dt = None
 
     def step(self, state_in, dt, want_error=True):

@@ -47,7 +47,11 @@ class IntegratedWienerTransition(namedtuple("_IWP", "wiener_process_dimension nu
         return P @ A @ Pinv, P @ Ql
 
     def projection_matrix(self, derivative_to_project_onto):
-        return np.kron(np.eye(self.wiener_process_dimension), self.projection_matrix_1d(derivative_to_project_onto))
+        # = np.kron(np.eye(d), e_q^T) (base/iwp.py:125-133), written directly: kron of a 4096-identity takes seconds
+        d, n = self.wiener_process_dimension, self.num_derivatives + 1
+        out = np.zeros((d, n * d))
+        out[np.arange(d), np.arange(d) * n + derivative_to_project_onto] = 1.0
+        return out
 
     def projection_matrix_1d(self, derivative_to_project_onto):
         return np.eye(1, self.num_derivatives + 1, derivative_to_project_onto)

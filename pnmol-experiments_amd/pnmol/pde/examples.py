@@ -167,11 +167,14 @@ def spruce_budworm_1d(*, bbox=None, t0=0.0, tmax=10.0, diffusion_rate=0.1, y0_fu
     def df_spruce(_, x, c=growth_rate):
         return np.diag(c * (1.0 - 2.0 * np.asarray(x)))
 
+    def df_diagonal_spruce(_, x, c=growth_rate):   # (the reference passes df_diagonal=None; the Jacobian IS diagonal)
+        return c * (1.0 - 2.0 * np.asarray(x))
+
     cls = {"dirichlet": problems.SemiLinearEvolutionDirichlet, "neumann": problems.SemiLinearEvolutionNeumann}.get(bcond)
     if cls is None:
         raise ValueError
     return cls(t0=t0, tmax=tmax, y0_fun=y0_fun, bbox=bbox, diffop=diffops.laplace(), diffop_scale=diffusion_rate,
-               f=f_spruce, df=df_spruce, df_diagonal=None)
+               f=f_spruce, df=df_spruce, df_diagonal=df_diagonal_spruce)
 
 
 # Initial-condition defaults; they adhere to Dirichlet conditions (examples.py:344-357)

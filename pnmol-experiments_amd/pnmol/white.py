@@ -34,12 +34,27 @@ class _WhiteNoiseEK1Base(pdefilter.PDEFilter):
     def initialize_iwp(self, pde):
         """Gamma = chol(k(X, X^T)); IWP prior; E0, E1 (white.py:82-94)."""
         X = pde.mesh_spatial.points
-        diffusion_state_sqrtm = np.linalg.cholesky(self.spatial_kernel(X, X.T))
+        gram = self.spatial_kernel(X, X.T)
+        self._last_gram = gram          # (handed to the device filter as it is: no Gamma Gamma^T product, `_bind`)
+        diffusion_state_sqrtm = self._cholesky(gram)
         prior = iwp.IntegratedWienerTransition(num_derivatives=self.num_derivatives,
                                                wiener_process_dimension=pde.y0.shape[0],
                                                wp_diffusion_sqrtm=diffusion_state_sqrtm)
         return prior, prior.projection_matrix(0), prior.projection_matrix(1), diffusion_state_sqrtm
 
+    # Gamma = chol(K) on the device (`pnmol_cholesky_lower`, SURVEY row f4) from d >= CHOLESKY_ON_DEVICE_FROM mesh points on
+    # (PNMOL_CHOL_ON_DEVICE=0/1 forces it off / on); LAPACK on the host below that (the factors agree to rounding:
+    # tests/test_gpu_assembly.py)
+    CHOLESKY_ON_DEVICE_FROM = 2048
+
+    def _cholesky(self, gram):
+        mode = os.environ.get("PNMOL_CHOL_ON_DEVICE", "")
+        on_device = gram.shape[0] >= self.CHOLESKY_ON_DEVICE_FROM if mode not in ("0", "1") else mode == "1"
+        if on_device:
+            return (self._context or _hip.Context.default()).cholesky(gram)
+        return np.linalg.cholesky(gram)
+
+    _last_gram = None
     _context = None   # set to an `_hip.Context` to run this solver on its own device / stream
     # Build-side option (SURVEY.md section 5; the reference is fp64 throughout, src/pnmol/__init__.py:9-11):
     # "f32" keeps the covariance and its bulk kernels in fp32 (include/pnmol_hip.h, pnmol_filter_desc.dtype;
@@ -54,10 +69,11 @@ class _WhiteNoiseEK1Base(pdefilter.PDEFilter):
             raise ValueError('dtype="f32" keeps the covariance in single precision, which is only accurate for '
                              "num_derivatives = 1 (DESIGN.md section 11); use the fp64 path")
         ctx = self._context or _hip.Context.default()
+        gram = self._last_gram if (self._last_gram is not None and self._last_gram.shape == gamma.shape) else gamma @ gamma.T
         self._device_filter = _hip.Filter(ctx, L=pde.L, B=pde.B, E_sqrtm=pde.E_sqrtm, R_sqrtm=pde.R_sqrtm, Gamma=gamma,
-                                          num_derivatives=self.num_derivatives, dtype=self.dtype)
+                                          num_derivatives=self.num_derivatives, dtype=self.dtype, K=gram)
         self._device_pde = pde
-        self._gram = gamma @ gamma.T
+        self._gram = gram
         self._error_models = {}
 
     # True: the reference's own two `update_sqrt` calls, on the device (below); False: closed form on the host (O(d^3) LAPACK);
@@ -75,7 +91,9 @@ class _WhiteNoiseEK1Base(pdefilter.PDEFilter):
 
         ctx = self._device_filter.ctx
         n, d, nB = self.num_derivatives + 1, pde.L.shape[0], pde.B.shape[0]
-        C0_raw = np.kron(gamma, self.diffuse_prior_scale * np.eye(n))
+        C0_raw = np.zeros((n * d, n * d))               # = np.kron(gamma, c I_n) (white.py:21-24), without kron's temporaries
+        for a in range(n):
+            C0_raw[a::n, a::n] = self.diffuse_prior_scale * gamma
         C0_y0, k_y0, _ = dsqrt.update_sqrt(self.E0, C0_raw, 1e-10 * np.eye(d), ctx=ctx)
         m0_y0 = k_y0 @ pde.y0
         M, shift = self._linearize(pde, m0_y0[0::n], pde.t0)
@@ -210,6 +228,10 @@ class _WhiteNoiseEK1Base(pdefilter.PDEFilter):
 
     semilinear = False
 
+    @staticmethod
+    def _jacobian_diagonal(pde, m_at, t):
+        return None
+
     def attempt_step(self, state, dt, pde):
         """One predict + update + calibrate step on the GPU (white.py:96-146); `state` is not modified."""
         dev_in = self._device_state_of(state, pde)
@@ -218,12 +240,19 @@ class _WhiteNoiseEK1Base(pdefilter.PDEFilter):
             # predicted point comes back once per step; the new stencil rows and shift go to the device
             flt = self._device_filter
             m_at = flt.predict_mean(dev_in, dt)
-            M, shift = self._linearize(pde, m_at, state.t + dt)
-            flt.set_operator(M, shift)
-            if self.error_model_on_host:
-                flt.set_error_model(dt, *self._error_model(pde, dt, M=M))
-            else:
+            jdiag = self._jacobian_diagonal(pde, m_at, state.t + dt)
+            if jdiag is not None and not self.error_model_on_host:
+                # pointwise nonlinearity (`df_diagonal`): 2 d numbers go to the device, which patches its stencil rows itself
+                fx = np.asarray(pde.f(state.t + dt, m_at), dtype=np.float64)
+                flt.set_operator_diagonal(jdiag, jdiag * m_at - fx)
                 flt.prepare_error_model(dt)
+            else:
+                M, shift = self._linearize(pde, m_at, state.t + dt)
+                flt.set_operator(M, shift)
+                if self.error_model_on_host:
+                    flt.set_error_model(dt, *self._error_model(pde, dt, M=M))
+                else:
+                    flt.prepare_error_model(dt)
         else:
             self._ensure_error_model(pde, dt)
         dev_out, info, error = self._device_filter.step(dev_in, dt)
@@ -293,6 +322,14 @@ class SemiLinearWhiteNoiseEK1(_WhiteNoiseEK1Base):
         fx = np.asarray(pde.f(t, m_at), dtype=np.float64)
         Jx = np.asarray(pde.df(t, m_at), dtype=np.float64)
         return pde.L + Jx, Jx @ m_at - fx
+
+    @staticmethod
+    def _jacobian_diagonal(pde, m_at, t):
+        """diag(J_x) where the problem says its Jacobian is diagonal (`df_diagonal`, pde/problems.py:11-42), else None."""
+        dfd = getattr(pde, "df_diagonal", None)
+        if dfd is None or pde.L.shape[0] != pde.L.shape[1]:
+            return None
+        return np.asarray(dfd(t, m_at), dtype=np.float64)
 
     def solve_marginals(self, pde, *, num_steps=None):
         raise TypeError("solve_marginals keeps the loop on the device and needs a linear PDE; use solve()")

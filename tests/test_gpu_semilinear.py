@@ -71,3 +71,19 @@ def test_adaptive_steps_follow_the_oracle(hip_ctx):
     assert sol.info == osol.info and sol.info["num_attempted_steps"] >= sol.info["num_steps"] > 3
     np.testing.assert_allclose(sol.t, osol.t, rtol=1e-9)
     np.testing.assert_allclose(sol.mean[:, 0], osol.mean[:, 0], rtol=1e-5, atol=1e-5 * np.abs(osol.mean).max())
+
+
+def test_diagonal_operator_update_equals_the_dense_one(hip_ctx):
+    """`pnmol_filter_set_operator_diagonal` (pointwise nonlinearity: the device patches its stencil rows from diag(J_x))
+    against `pnmol_filter_set_operator` with the dense J_x + L: the same ELL image, hence the same numbers, bit for bit."""
+    dt, K = 2.0 ** -6, 10
+    runs = []
+    for diagonal in (True, False):
+        pde, solver, _, _ = _pair(48, 1.0 / 47, dt, K * dt, "dirichlet", prior="matern")
+        assert pde.df_diagonal is not None
+        if not diagonal:
+            pde.df_diagonal = None
+        runs.append([(s.y.mean.copy(), s.y.marginal_var.copy(), s.error_estimate, s.diffusion_squared_local)
+                     for s, _ in list(solver.solution_generator(pde))[1:]])
+    for (m1, v1, e1, s1), (m2, v2, e2, s2) in zip(*runs):
+        assert np.array_equal(m1, m2) and np.array_equal(v1, v2) and np.array_equal(e1, e2) and s1 == s2
