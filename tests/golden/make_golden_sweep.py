@@ -7,6 +7,7 @@ Workload = bench.py's / BASELINE config 4: 1-D heat equation, Dirichlet, dx = 1/
 prior Matern52 + WhiteNoise, nu = 2, dt = 2^-7 (no runt step), diffusion sweep kappa_g = 0.01 * 10^(g/7), g = 0..7.
   N = 512 : 100 steps for each of the 8 problems  (about 1-2 min each on 8 cores)
   N = 1024: 24 steps for g = 0, 3 and 7           (about 8 s per step)
+  N = 256 : 100 steps, kappa = 0.05 (BASELINE config 2; the value bench.py's secondary point runs) -> ..._n256_nu2_kc.npz
 Stored per problem: t (T+1), means (T+1, d) = sol.mean[:, 0], stds (T+1, d) = sqrt(diag(C C^T) E0^T)
 (experiments/figure1.py:76-80), sigma2 (T) = diffusion_squared_local with canonical factor signs,
 kappa.  float64, compressed.  Run:  python tests/golden/make_golden_sweep.py [512|1024] [g ...]
@@ -22,8 +23,8 @@ sys.path.insert(0, str(ROOT / "oracle"))
 import pnmol_oracle as o  # noqa: E402
 
 DT = 2.0 ** -7
-STEPS = {512: 100, 1024: 24}
-PROBLEMS = {512: list(range(8)), 1024: [0, 3, 7]}
+STEPS = {512: 100, 1024: 24, 256: 100}
+PROBLEMS = {512: list(range(8)), 1024: [0, 3, 7], 256: ["c"]}
 
 
 def kappa_of(g, count=8, lo=0.01, hi=0.1):   # pnmol/batch.py:diffusion_sweep (kept in step by tests/test_sweep_golden.py)
@@ -31,7 +32,7 @@ def kappa_of(g, count=8, lo=0.01, hi=0.1):   # pnmol/batch.py:diffusion_sweep (k
 
 
 def run(N, g):
-    K, kappa = STEPS[N], kappa_of(g)
+    K, kappa = STEPS[N], (0.05 if g == "c" else kappa_of(g))
     pde = o.heat_1d_discretized(bbox=[0.0, 1.0], dx=1.0 / (N - 1), stencil_size_interior=3, stencil_size_boundary=3,
                                 t0=0.0, tmax=K * DT, diffusion_rate=kappa, kernel=o.SquareExponential(),
                                 nugget_gram_matrix_fd=0.0, bcond="dirichlet")
@@ -56,5 +57,5 @@ def run(N, g):
 
 if __name__ == "__main__":
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-    for g in ([int(a) for a in sys.argv[2:]] or PROBLEMS[N]):
+    for g in ([(a if a == "c" else int(a)) for a in sys.argv[2:]] or PROBLEMS[N]):
         run(N, g)

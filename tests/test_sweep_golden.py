@@ -111,3 +111,21 @@ def test_sweep_n1024(g):
     # |Ls^-T z|^2 / m (quirk Q1) at N=1024: values of 1e4..1e7, cond(S) ~1e12 -- 1e-4 relative between two factorisation
     # orders (observed 9.7e-5 at kappa = 0.1); mean and std above are what north_star's tolerances are about
     np.testing.assert_allclose(sig, f["sigma2"], rtol=5e-4)
+
+
+def test_fixture_n256_is_config_2():
+    f = _load(256, "c")
+    assert float(f["kappa"]) == 0.05 and tuple(f["config"]) == (256, 2, DT, 100)
+    assert f["means"].shape == (101, 256) and f["stds"].shape == (101, 256) and f["sigma2"].shape == (100,)
+    np.testing.assert_array_equal(f["t"], DT * np.arange(101))
+
+
+@pytest.mark.gpu
+def test_full_length_n256():
+    """BASELINE config 2 (N=256, nu=2, fp64; the kappa of bench.py's secondary point) at full length: every one of its 100
+    steps against the oracle fixture, mean 1e-5 / std 1e-4."""
+    f, pde, solver = _solver_on_own_stream(256, "c", 100)
+    t, means, stds, sig, _ = solver.solve_marginals(pde)
+    assert np.array_equal(t, f["t"])
+    assert_mean_std_parity(means, stds, f["means"], f["stds"])
+    np.testing.assert_allclose(sig, f["sigma2"], rtol=2e-5)
