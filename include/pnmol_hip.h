@@ -190,6 +190,10 @@ int pnmol_filter_last_steps_ms(pnmol_filter* f, float* ms);
  * which: 0 = predicted covariance (Dp*Dp, derivative-major padded), 1 = G work matrix,
  * 2 = F factor matrix [Ls; W; r^T], 3 = predicted mean (Dp), 4 = z (mp).  `count` doubles. */
 int pnmol_filter_debug_read(pnmol_filter* f, int which, double* dst, long count);
+/* Test hook: fills the buffers the sweep kernels hand data over through (F, the L_jj^-1 tiles, the feed / scratch tiles) with
+ * NaN, as stale contents of an earlier launch.  A following step must give the same bits as without it
+ * (tests/test_gpu_parity.py::test_stale_hand_over_buffers_are_never_read): every reader takes published data only. */
+int pnmol_filter_debug_poison(pnmol_filter* f);
 int pnmol_filter_dims(const pnmol_filter* f, int* d, int* n, int* m, int* dp, int* mp);
 
 #ifdef __cplusplus

@@ -964,8 +964,17 @@ __global__ __launch_bounds__(256) void k_panel(double* __restrict__ G, double* _
 // Coherence protocol (measured in tools/flag_hop_bench.hip; the XCDs' L2s are not coherent with each other):
 // producers write shared tiles with agent-scope (write-through, sc1) stores, wait for them (s_waitcnt) and then set
 // the flag; consumers poll with agent-scope loads and execute an agent-scope acquire fence (buffer_inv sc1) before
-// touching the data.  A dependency always points to a LOWER block index, and workgroups are dispatched in index
-// order, so waiting cannot deadlock; all spins are bounded anyway (then `info` = -2 and every workgroup bails out).
+// touching the data.
+// Forward progress.  In k_sweep every dependency points to a LOWER block index, and each XCD dispatches its workgroups in
+// index order (block b goes to XCD b mod 8) -- but the eight queues advance independently, so "the producer was dispatched
+// before me" holds per XCD only.  In k_sweep_rl one dependency even points upwards: the chain workgroup (block 0) waits for
+// the feed of row block J+1.  With ONE sweep on the device every workgroup is resident from the start (RT + pairs <= 256
+// CUs) and none of this matters.  With SEVERAL sweeps in flight a workgroup can spin on a producer that has no CU yet; it
+// then gets one whenever any workgroup on that XCD retires, which the workgroups that do not wait (or whose producers are
+// resident) keep doing -- in practice sixteen sweeps in flight run through (tests/test_gpu_parity.py::
+// test_sixteen_problems_in_flight), but it is not a proof: every spin is therefore bounded (SWEEP_SPIN_LIMIT polls, about
+// 0.2 s), a sweep that exceeds it reports `info` = -2 (return code -2, the step is lost, nothing hangs), and a caller that
+// wants a guarantee keeps at most one sweep per 256 / (RT + pairs) of the device in flight.
 // ------------------------------------------------------------------------------------------
 constexpr int SWEEP_SPIN_LIMIT = 1 << 18;
 #ifdef PNMOL_SWEEP_STAMP
@@ -2350,9 +2359,10 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
         return;
     }
     // !XL: block 1 + I is row block I.  XL: blocks 8 s, s = 1 .. CB-1, are the row blocks of S (I = s: the chain workgroup's
-    // XCD) and the blocks between them are empty -- every dependency must point to a LOWER block index: workgroups are
-    // dispatched in index order, and when several sweeps share the device a workgroup that spins on a block which has no
-    // CU yet would never let it have one.  The remaining row blocks and the down-date pairs follow behind block 8 (CB-1).
+    // XCD) and the blocks between them are empty -- the row blocks of W / Ls^-T and the down-date pairs wait for these
+    // (lower) blocks only, and an XCD dispatches in index order.  (The chain workgroup itself waits for the feed of row
+    // block J+1, a HIGHER index on the same XCD: see "Forward progress" at SWEEP_SPIN_LIMIT.)  The remaining row blocks and
+    // the down-date pairs follow behind block 8 (CB-1).
     int I;
     if constexpr (XL) {
         const int b = bx, nslot = 8 * (CB - 1) + 1;
@@ -2979,6 +2989,21 @@ __global__ __launch_bounds__(256) void k_readout(const double* __restrict__ mean
         __syncthreads();
         if (threadIdx.x < 3) rec[threadIdx.x] = sred[threadIdx.x][0] + sred[threadIdx.x][1] + sred[threadIdx.x][2] + sred[threadIdx.x][3];
     }
+}
+
+// Test hook (pnmol_filter_debug_poison): NaN into every buffer the sweep hands data over through -- F, the lower parts of
+// the L_jj^-1 tiles (their upper-right quadrants are zero by contract and never written), the feed / scratch tiles -- by
+// plain stores from workgroups on all XCDs, i.e. as a previous launch would have left them in the L2s and in memory.
+__global__ __launch_bounds__(256) void k_poison(double* __restrict__ F, long nF, double* __restrict__ Linv, long nL,
+                                                double* __restrict__ hs, long nH) {
+    const double bad = __longlong_as_double(0x7ff8dead0000beefLL);
+    const long stride = (long)gridDim.x * 256;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nF; e += stride) F[e] = bad;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nL; e += stride) {
+        const int r = (int)((e / NB) % NB), c = (int)(e % NB);
+        if (!(r < 16 && c >= 16)) Linv[e] = bad;
+    }
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nH; e += stride) hs[e] = bad;
 }
 
 // M = L + diag(j) on the device (semilinear EK1 with a pointwise nonlinearity, white.py:192-208: J_x = diag(df/du)): the
@@ -4494,6 +4519,17 @@ int pnmol_filter_prepare_steps(pnmol_filter* f, pnmol_state* s, int k, double dt
         return -2;
     }
     return rc;
+}
+
+int pnmol_filter_debug_poison(pnmol_filter* f) {
+    if (!f) return -1;
+    pnmol_ctx* ctx = f->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const long nF = (long)f->RT * NB * f->mp, nL = (long)f->CB * NB * NB;
+    const long nH = (long)std::max(f->CB * f->CB, 2 * f->CB + 2) * NB * NB;
+    k_poison<<<1024, 256, 0, ctx->stream>>>(f->F, nF, f->Linv, nL, f->hs_scratch, nH);
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
 }
 
 int pnmol_filter_last_steps_ms(pnmol_filter* f, float* ms) {

@@ -82,6 +82,7 @@ SYMBOLS = {
     "pnmol_filter_last_steps_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "pnmol_filter_prepare_error_model": (ctypes.c_int, [_vp, ctypes.c_double]),
     "pnmol_filter_debug_read": (ctypes.c_int, [_vp, ctypes.c_int, _c_double_p, ctypes.c_long]),
+    "pnmol_filter_debug_poison": (ctypes.c_int, [_vp]),
     "pnmol_filter_dims": (ctypes.c_int, [_vp] + [ctypes.POINTER(ctypes.c_int)] * 5),
     "pnmol_filter_sweep_layout": (ctypes.c_int, [_vp] + [ctypes.POINTER(ctypes.c_int)] * 2),
     # include/pnmol_sqrt.h
@@ -366,6 +367,9 @@ class Filter:
         ms = ctypes.c_float(0.0)
         self.lib.pnmol_filter_last_steps_ms(self.handle, ctypes.byref(ms))
         return float(ms.value)
+
+    def debug_poison(self):
+        self.ctx.check(self.lib.pnmol_filter_debug_poison(self.handle), "pnmol_filter_debug_poison")
 
     def debug_read(self, which, count):
         out = np.empty(int(count))

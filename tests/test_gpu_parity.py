@@ -7,6 +7,8 @@ import scipy.linalg
 import pnmol_oracle as oracle
 from helpers import assert_mean_std_parity, make_pair, to_device_layout
 
+DT = 2.0 ** -7
+
 pytestmark = pytest.mark.gpu
 
 
@@ -379,3 +381,66 @@ def test_filters_alive_together_agree_bit_for_bit(hip_ctx, N):
         runs.append(solver.solve_marginals(pde))
     for r in runs[1:]:
         assert np.array_equal(runs[0][1], r[1]) and np.array_equal(runs[0][2], r[2]) and np.array_equal(runs[0][3], r[3])
+
+
+@pytest.mark.parametrize("N", [256, 1024])
+def test_stale_hand_over_buffers_are_never_read(hip_ctx, N):
+    """the cross-workgroup hand-over of the sweep kernels relies on "a tile is only read behind its flag, and
+    the first touch after the kernel-start invalidate is fresh".  A reader that took a line from an earlier launch (round 2
+    had one: 8-byte sc1 loads served from the XCD's L2) would go unnoticed while that launch wrote nearly the same numbers.
+    Here every hand-over buffer (F, the L_jj^-1 tiles, the feed / scratch tiles) is filled with NaN by another launch between
+    calls: the steps must give the same bits as without it.  N=256: k_sweep_rl; N=1024: k_sweep."""
+    import pnmol
+    K = 6
+    pde, solver, _, _ = make_pair(N, 2, DT, 2 * K)
+    state = solver.initialize(pde)
+    solver._ensure_error_model(pde, DT)
+    flt, dev = solver._device_filter, state.y.device_state
+    clean, dirty = flt.new_state(), flt.new_state()
+    for st in (clean, dirty):
+        st.set(pde.t0, dev.mean(), dev.cov())
+    m1, s1, i1 = flt.steps(clean, K, DT)                    # the same call sequence without the poison
+    o1, info1, err1 = flt.step(clean, DT)
+    m1b, s1b, i1b = flt.steps(o1, K - 1, DT)
+    flt.debug_poison()
+    m2, s2, i2 = flt.steps(dirty, K, DT)
+    flt.debug_poison()
+    o, info, err = flt.step(dirty, DT)                      # the self-contained single step as well
+    flt.debug_poison()
+    m2b, s2b, i2b = flt.steps(o, K - 1, DT)
+    assert np.all(np.isfinite(m2)) and np.all(np.isfinite(s2)) and all(x.info == -1 for x in i2)
+    assert np.array_equal(m1, m2) and np.array_equal(s1, s2)
+    assert [x.diffusion_squared_local for x in i1] == [x.diffusion_squared_local for x in i2]
+    assert np.array_equal(o1.mean(), o.mean()) and np.array_equal(err1, err)
+    assert info1.diffusion_squared_local == info.diffusion_squared_local
+    assert np.array_equal(m1b, m2b) and np.array_equal(s1b, s2b)
+    assert [x.diffusion_squared_local for x in i1b] == [x.diffusion_squared_local for x in i2b]
+
+
+def test_sixteen_problems_in_flight():
+    """a dependency of the sweep kernel may point to a workgroup that has no CU yet (the chain workgroup
+    waits for the feed of a higher block index; dispatch order holds per XCD only), so with many sweeps in flight forward
+    progress rests on the bounded spins and on workgroups retiring.  Sixteen problems (twice the benchmark's batch) in
+    flight on one device must finish without a timed-out wait (info == -1 everywhere) and bit-identical to their serial runs."""
+    import pnmol
+    from pnmol import _hip, batch
+    K, B = 10, 16
+    runs = []
+    for g in range(B):
+        pde = pnmol.pde.examples.heat_1d_discretized(tmax=K * DT, dx=1.0 / 255, diffusion_rate=batch.diffusion_sweep(g % 8, 8),
+                                                     kernel=pnmol.kernels.SquareExponential(), bcond="dirichlet")
+        solver = pnmol.white.LinearWhiteNoiseEK1(num_derivatives=2, steprule=pnmol.odetools.step.Constant(DT),
+                                                 spatial_kernel=pnmol.kernels.Matern52() + pnmol.kernels.WhiteNoise())
+        solver._context = _hip.Context(0)
+        state = solver.initialize(pde)
+        solver._ensure_error_model(pde, DT)
+        flt, dev = solver._device_filter, state.y.device_state
+        ref = flt.new_state()
+        ref.set(pde.t0, dev.mean(), dev.cov())
+        runs.append((solver, flt, dev, flt.steps(ref, K, DT)))
+    for _, flt, dev, _ in runs:
+        flt.steps_begin(dev, K, DT)
+    for _, flt, dev, (m_seq, s_seq, i_seq) in runs:
+        m, s, infos = flt.steps_end(dev)
+        assert all(o.info == -1 for o in infos)
+        assert np.array_equal(m, m_seq) and np.array_equal(s, s_seq)

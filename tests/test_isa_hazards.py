@@ -23,6 +23,7 @@ def _scan(src, tmp_path, *defines):
                     "--cuda-device-only", *defines, str(src), "-o", str(out)], check=True)
     res = subprocess.run([sys.executable, str(ROOT / "tools" / "mfma_hazard_scan.py"), str(out), "10"],
                          check=True, capture_output=True, text=True).stdout
+    _scan.sc1x2 = int(res.strip().splitlines()[-2].split()[0])     # "N 8-byte sc1 loads" (second check of the scanner)
     return int(res.strip().splitlines()[-1].split()[0]), res
 
 
@@ -31,6 +32,8 @@ def _scan(src, tmp_path, *defines):
 def test_no_mfma_result_is_read_too_early(tmp_path, name):
     hits, report = _scan(CSRC / name, tmp_path)
     assert hits == 0, report
+    # hand-over data is never read with 8-byte sc1 loads (they were served stale L2 lines: DESIGN.md section 3a'')
+    assert _scan.sc1x2 == 0, report
 
 
 @pytest.mark.skipif(not pathlib.Path(HIPCC).exists(), reason="hipcc not available")

@@ -2,7 +2,12 @@
 section 3a''): an MFMA whose result registers are read by a VALU / LDS / VMEM instruction within a few instructions and with
 fewer than NEED wait states (s_nop, other instructions) in between -- looking through unconditional branches and into both
 successors of conditional ones.  hipcc normally inserts the s_nop; where an MFMA chain ended a conditional block it put
-the s_nop behind the first reads.  usage: mfma_hazard_scan.py file.s [NEED=10]"""
+the s_nop behind the first reads.  usage: mfma_hazard_scan.py file.s [NEED=10]
+
+Second check: 8-byte loads with sc1 (`*_load_dwordx2 ... sc1`).  Such loads of data another workgroup had
+published returned the PREVIOUS launch's bytes from the XCD's L2 in k_sweep_rl (DESIGN.md section 3a'', hand-over lesson 1;
+the guide's table of validated hand-offs lists dword and dwordx4 only): hand-over data is read with 16-byte sc1 loads, flags
+with 4-byte ones, and no kernel of the library may contain the 8-byte form.  Reported on the line before the last."""
 import re, sys
 
 path = sys.argv[1]
@@ -81,4 +86,8 @@ for i, (t, ln) in enumerate(code):
                     break      # overwritten
                 ws += 1
             k += 1
+bad8 = [(t, ln) for t, ln in code if re.match(r"^(global|buffer|flat)_load_dwordx2\b", t) and re.search(r"\bsc1\b", t)]
+for t, ln in bad8:
+    print(f"{path}:{ln}: 8-byte sc1 load '{t}'")
+print(f"{len(bad8)} 8-byte sc1 loads")
 print(f"{hits} suspicious reads (fewer than {NEED} wait states behind an MFMA)")
