@@ -1947,6 +1947,29 @@ __global__ __launch_bounds__(256) void k_sweep(const double* __restrict__ G, dou
 //   fdiagL[CBp], fnewL[CBp]  copies of fdiag / fnew that are stored plainly, for the pollers on the chain workgroup's XCD (XL)
 //   frowL[CBp]        frow of the row blocks of S for the same pollers; ahead of frow for a row's last ordinary tile (see there)
 constexpr int RL_REP = 8;
+// The late row blocks of S are split over two workgroups (XL layout only): row block I >= S_SPLIT_FROM is "part A", tiles
+// 0 .. S_SPLIT_H-1 (an ordinary row block that stops there and publishes all its tiles), and "part B", tiles S_SPLIT_H .. I-1
+// and the feed.  Why: a row block's step costs ~3.5 us + 0.45 us per tile it still has to update, so row block I needs
+// 3.5 (I-1) + 0.45 I^2 / 2 us in all and has 5.5 I us until the chain workgroup wants its feed -- from I = 10 on it falls
+// behind, and the chain's period grew from 5.3 us (J <= 2) to 7-12 us (J >= 10): profiles/r03_microbench/sweep_timeline_a_early_publication.log.
+constexpr int S_SPLIT_FROM = 11, S_SPLIT_H = 9;
+__host__ __device__ inline int s_split_count(int CB, bool xl) { return (xl && CB > S_SPLIT_FROM) ? CB - S_SPLIT_FROM : 0; }
+// The row blocks of W are split the same way (both layouts): part A = tiles 0 .. W_SPLIT_H-1, part B = the rest, the vector
+// ops.  A row block of W needs 17 x ~4.2 us of step overhead + 136 tile updates x 0.42 us = ~125 us for its 17 steps and
+// was the last thing the sweep waited for once the chain had become faster; the halves need ~63 us each.  The parts B
+// sit behind all other row blocks in the block order (they wait for their parts A), the down-date pairs behind them.
+// MEASURED AND SWITCHED OFF (PNMOL_W_SPLIT=1 at build time turns it on): the halves need ~63 us each as predicted (parts A
+// done at 78 us), but 48 more workgroups make 273 for 256 CUs -- 250 of them on the seven XCDs that are not the chain's --
+// and the 26 down-date pairs that get a CU only when the parts A retire finish at 149 us: 160 us per step against 144
+// (gpurun r3u).  The rows of W are made faster instead (eager bulk update, below).
+constexpr int W_SPLIT_H = 11;
+#ifndef PNMOL_W_SPLIT
+#define PNMOL_W_SPLIT 0
+#endif
+__host__ __device__ inline int w_split_count(int RT, int CB) {
+    const int RBW = RT - 2 * CB - 1;
+    return (PNMOL_W_SPLIT && RBW > 0 && CB > W_SPLIT_H + 1) ? RBW : 0;
+}
 struct RlFlags {
     int frow, fabort, fxcc, ffeed, fdiag, fnew, fcol, fdiagL, fnewL, frowL, CBp, total;
 };
@@ -2246,6 +2269,17 @@ __device__ __forceinline__ void sweep_chain_role(ChainLds& C, const double* __re
                                                Linv + (long)J * NB * NB, info, J * NB, C.sd[J & 1], smax, C.sLinv, pivtol);
         CHAIN_TRACE_W(J, 1, 3);
         CHAIN_TRACE_W(J, 6, 1);
+        // XL: wave 1, which has just finished L_JJ^-1, sends it to the row blocks of S on this XCD NOW -- before this
+        // workgroup waits for the feed of row block J+1.  (Round 2 published it behind that wait: row block J+2's
+        // TRSM with L_JJ^-1, hence its feed, hence the next wait, started only when the feed of row block J+1 had
+        // arrived -- a cycle  feed(J+1) -> L_JJ^-1 out -> TRSM, feed(J+2)  of 6.2 us around a chain that needs 4.5.)
+        if (XL && w == 1 && J + 1 < CB) {
+            TileRegs t1;
+            tile_regs_from_lds(t1, C.sLinv, l);  // (this wave's own LDS writes + the zero quadrant set at kernel start)
+            tile_regs_store<0>(t1, rlinv, (unsigned)(J * NB * NB * 8), NB, l);
+            drain_vmem();
+            if (l == 0) l2_flag_st(rflags, fl.fdiagL + J, 1);
+        }
         // w1 has left L^-1 in C.sLinv.  w2 publishes it behind the next block's TRSM: the other row blocks need it, the
         // next diagonal block does not.
         if (J + 1 == CB) {
@@ -2272,8 +2306,7 @@ __device__ __forceinline__ void sweep_chain_role(ChainLds& C, const double* __re
         TileRegs tl;
         if (w == 2) {
             if constexpr (XL) {
-                tile_regs_from_lds(tl, C.sLinv, l);
-                tile_regs_store<0>(tl, rlinv, (unsigned)(J * NB * NB * 8), NB, l);
+                tile_regs_from_lds(tl, C.sLinv, l);  // (for the write-through copy below; wave 1 has served this XCD)
             } else {
                 wt_rows_from_lds<8>(rlinv, (unsigned)(J * NB * NB * 8), NB, C.sLinv, 0, l);
             }
@@ -2291,10 +2324,8 @@ __device__ __forceinline__ void sweep_chain_role(ChainLds& C, const double* __re
         __syncthreads();  // X complete, flags of the next factorisation zeroed
         CHAIN_TRACE(J, 3);
         if (w == 2) {
-            drain_vmem();
-            if constexpr (XL) {
-                if (l == 0) l2_flag_st(rflags, fl.fdiagL + J, 1);
-            } else {
+            if constexpr (!XL) {
+                drain_vmem();
                 if (l < RL_REP) flag_st(fdiag_all + l * CBp + J, 1);  // all copies, one store instruction
             }
         }
@@ -2363,12 +2394,20 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
     // (lower) blocks only, and an XCD dispatches in index order.  (The chain workgroup itself waits for the feed of row
     // block J+1, a HIGHER index on the same XCD: see "Forward progress" at SWEEP_SPIN_LIMIT.)  The remaining row blocks and
     // the down-date pairs follow behind block 8 (CB-1).
-    int I;
+    int I, part = 0;  // part: 0 whole row block, 1 / 2 = parts A / B of a split row block of S (S_SPLIT_FROM)
     if constexpr (XL) {
-        const int b = bx, nslot = 8 * (CB - 1) + 1;
+        const int nsplit = s_split_count(CB, true);
+        const int b = bx, nslot = 8 * (CB - 1 + nsplit) + 1;
         if (b < nslot) {
             if (b % 8 != 0) return;
-            I = b / 8;
+            const int sidx = b / 8;
+            if (sidx < CB) {
+                I = sidx;
+                part = (nsplit > 0 && I >= S_SPLIT_FROM) ? 1 : 0;
+            } else {  // (the parts B follow the rows of S on the same XCD: they wait for their parts A, lower block indices)
+                I = S_SPLIT_FROM + (sidx - CB);
+                part = 2;
+            }
         } else {
             // ... on the seven other XCDs: the chain workgroup's XCD (32 CUs) keeps its CUs for the CB workgroups above --
             // with every eighth of the remaining workgroups on it as well, some of them found no CU for most of the sweep
@@ -2380,16 +2419,20 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
         I = bx - 1;
     }
 #ifdef PNMOL_SWEEP_STAMP
-    if (tid == 0) L.stamp_id = 1 + I;  // (visible to everybody behind the workgroup's first barrier; only thread 0 and
+    if (tid == 0) L.stamp_id = part == 1 ? 200 + I : 1 + I;  // (visible to everybody behind the workgroup's first barrier; only thread 0 and
                                        //  lane-0 threads behind later barriers stamp)
 #endif
     {
         const int zb = RT - CB - 1;  // the r^T block is dealt right behind the rows of S (see k_sweep)
         if (I >= CB && I <= zb) I = (I == CB) ? zb : I - 1;
     }
-    const bool chain = I < CB;
-    if constexpr (FUSED) {
-        if (I >= RT) {
+    const int nwsplit = w_split_count(RT, CB);
+    if (I >= RT && I < RT + nwsplit) {  // part B of row block CB + (I - RT) of W
+        I = CB + (I - RT);
+        part = 2;
+    } else if (I >= RT) {
+        I -= nwsplit;                   // (the down-date pairs: logical indices RT ..)
+        if constexpr (FUSED) {
             if (tid == 0) {
                 L.dead = 0;
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -2397,12 +2440,15 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
             __syncthreads();
             SWEEP_STAMP(0);
             sweep_downdate_role<N, true>(L, dd, F, ld, CB, CB, frow, fabort, info, I - RT, tid, l, w, *ctr - 1);
-            return;
         }
+        return;
+    } else if (nwsplit > 0 && I >= CB && I < RT - CB - 1) {
+        part = 1;                       // part A of a row block of W
     }
+    const bool chain = I < CB;
     if (chain && I == 0) return;  // (block (0,0) is the chain workgroup's own)
     if (tid == 0) {
-        L.dead = 0, L.pub = 0, L.pubcnt = 0, L.rdiag = 0, L.rnew = 0, L.rcol = 0, L.rzb = 0;
+        L.dead = 0, L.pub = 0, L.pubcnt = part == 2 ? 4 * (I < CB ? S_SPLIT_H : W_SPLIT_H) : 0, L.rdiag = 0, L.rnew = 0, L.rcol = 0, L.rzb = 0;
         L.seen[0] = 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // one invalidate per workgroup (see k_sweep)
     }
@@ -2414,17 +2460,20 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
     const int offC = (wr * 16 + fk) * TLD + colC;
     // Steps 0 .. last end with X_j; a chain row runs one more, incomplete step (j = I - 1: tile I-1 with all panels but
     // the last, then fed to the chain workgroup with -D') and holds tiles 0 .. I-1.
-    const int last = chain ? I - 2 : CB - 1;
-    const int ntiles = chain ? I : CB;
-    d4 n[MAXT];  // slot u: quadrant of -(tile j + u) at step j
+    const bool feeds = chain && part != 1;           // (part A of a split row block stops at tile S_SPLIT_H - 1 and feeds nothing)
+    const int hsplit = chain ? S_SPLIT_H : W_SPLIT_H;
+    const int t0 = part == 2 ? hsplit : 0;           // first tile this workgroup owns
+    const int last = part == 1 ? hsplit - 1 : (chain ? I - 2 : CB - 1);
+    const int ntiles = part == 1 ? hsplit : (chain ? I : CB);   // (one past its last tile)
+    d4 n[MAXT];  // slot u: quadrant of -(tile j + u) at step j >= t0 (part B before its first step: tile t0 + u)
 #pragma unroll
     for (int t = 0; t < MAXT; ++t)
-        if (t < ntiles) {
+        if (t0 + t < ntiles) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) n[t][r] = -G[(rowC + 4 * r) * ld + (long)t * NB + colC];
+            for (int r = 0; r < 4; ++r) n[t][r] = -G[(rowC + 4 * r) * ld + (long)(t0 + t) * NB + colC];
         }
     d4 accD = {0, 0, 0, 0};  // quadrant of -D' (see k_sweep)
-    if (chain) {
+    if (feeds) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int rl = wr * 16 + fk + 4 * r, cl = colC;
@@ -2532,15 +2581,169 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
                 __builtin_amdgcn_sched_barrier(0);
             }
             SWEEP_TRACE_VM(j, 7);
+            if (with_syrk && XL && local) {
+                // (the feed step of a row block of S) tile (I, I-2), stored into the L2 at the end of the last ordinary step,
+                // has drained when the newest tile is here: flag it for the next row block now, not behind the feed
+                drain_vmem();
+                int lastw = 0;
+                if (l == 0) lastw = __hip_atomic_fetch_add(&L.pub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 3;
+                if (__builtin_amdgcn_readfirstlane(lastw) && l == 0 && I >= 2) l2_flag_st(rflags, fl.frowL + I, I - 1);
+            }
 #pragma unroll
             for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ax.v[s], b0.v[s], acc, 0, 0, 0);
             mfma_result_guard();
             if (flag_previous) flag_tile(j - 1);  // (b0 has arrived: so have the stores of tile j-1, issued before its load)
         }
     };
-    for (int j = 0; j <= last; ++j) {
+    if (part == 2) {
+        // Part B of a split row block of S.  Columns k = 0 .. t0-2: X_{I,k} comes from part A (tile (I, k) of F, same XCD),
+        // panel k goes onto ALL own tiles t0 .. I-1 (slots stay put) and onto D'.  Then X_{I,t0-1} is fetched into the LDS
+        // buffer the first ordinary step (j = t0) takes its "previous X" from, and that step finds everything as if this
+        // workgroup had run the steps before it.
+        const int* fsrc = (XL && local) ? flags + fl.frowL : frow;
+        for (int k = 0; k + (chain ? 1 : 0) < t0; ++k) {  // (a part B of W: all panels k < t0, see the eager loop below)
+            if (chain) {
+                relay_progress_min(fsrc + t0, I - t0 + 1, k + 1, known_col, &L.rcol, fabort, ww, w, l);  // rows t0 .. I: tile k out
+            } else {  // (a row block of W: all rows of S have published tile k; part A has published tile (I, k))
+                relay_progress(fcol, CB - 1, [CB](int q) { return CB - 2 - q; }, k + 1, known_col, &L.rcol, fabort, ww, w, l);
+                relay_wait_ge(frow + I, k + 1, &L.rzb, k + 1, fabort, ww, w);
+            }
+            Frag8 bx;
+            frag_ld(ax, F + ((long)I * NB + wr * 16 + fr) * ld + (long)k * NB + 8 * fk);
+            frag_ld(bx, F + ((long)I * NB + wc * 16 + fr) * ld + (long)k * NB + 8 * fk);
+#pragma unroll
+            for (int u0 = 0; u0 < 8; u0 += 4) {
+                Frag8 b[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (t0 + u0 + q < ntiles)
+                        frag_ld(b[q], F + ((long)(t0 + u0 + q) * NB + wc * 16 + fr) * ld + (long)k * NB + 8 * fk);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (t0 + u0 + q < ntiles) {
+#pragma unroll
+                        for (int s = 0; s < 8; ++s)
+                            n[u0 + q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax.v[s], b[q].v[s], n[u0 + q], 0, 0, 0);
+                    }
+            }
+            if (chain) {
+#pragma unroll
+                for (int s = 0; s < 8; ++s) accD = __builtin_amdgcn_mfma_f64_16x16x4f64(ax.v[s], bx.v[s], accD, 0, 0, 0);
+            }
+            mfma_result_guard();
+        }
+        if (chain) {
+        relay_wait_ge(fsrc + I, t0, &L.rzb, t0, fabort, ww, w);  // part A has published tile t0 - 1 (own relay word: the
+                                                                 // range polls above and below keep their meaning)
+        double* sXp = ((t0 - 1) & 1) ? L.sP[0] : L.sX;
+        tile_g2s(F + ((long)I * NB) * ld + (long)(t0 - 1) * NB, ld, sXp, tid);
+        __syncthreads();
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                accD = __builtin_amdgcn_mfma_f64_16x16x4f64(sXp[(wr * 16 + fr) * TLD + 8 * fk + s],
+                                                            sXp[(wc * 16 + fr) * TLD + 8 * fk + s], accD, 0, 0, 0);
+            mfma_result_guard();
+        }
+    }
+    // Rows of W, the r^T block, rows of Ls^-T: EAGER right-looking steps.  These row blocks lag behind the chain workgroup, so
+    // when X_j exists the whole column j of L -- tile (j+1, j) from the chain workgroup, tiles (t, j) of the later rows of
+    // S -- is out or about to be: panel j goes onto ALL remaining tiles at once, tile j+1 included, and the next step starts
+    // with a finished S_{j+1}.  Against the scheme of the rows of S below (newest panel j-1 on tile j, panel j-1 on the rest,
+    // then X_j) a step loses one poll, one dependent tile load, one 8-MFMA product with its LDS round trip -- 1.2-1.5 us of
+    // the ~4.2 us a step costs beside its tile updates -- and X_j is flagged right behind its stores instead of a step later.
+    // Same operations on the same operands in the same order per tile: bit-identical results.
+    if (!chain) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) L.sS[t0 & 1][offC + 4 * r * TLD] = -n[0][r];
+        __syncthreads();
+        bool pre_l = false;
+        for (int j = t0; j <= last; ++j) {
+            const double* sS = L.sS[j & 1];
+            SWEEP_TRACE(j, 0);
+            relay_progress(fdiag, CB, [](int) { return 1; }, j + 1, known_diag, &L.rdiag, fabort, ww, w, l);
+            SWEEP_TRACE(j, 5);
+            Frag8 bl;
+            if (pre_l) {
+                ring_wait(0);
+                ring_frag(bl, ringw + 512 * RING_LINV, fr, fk);
+            } else {
+                frag_ld(bl, Linv + (long)j * NB * NB + (wc * 16 + fr) * NB + 8 * fk);
+            }
+            d4 x = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                x = __builtin_amdgcn_mfma_f64_16x16x4f64(sS[(wr * 16 + fr) * TLD + 8 * fk + s], bl.v[s], x, 0, 0, 0);
+            double* sXj = (j & 1) ? L.sP[0] : L.sX;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sXj[offC + 4 * r * TLD] = x[r];
+            __syncthreads();  // X_j complete
+            SWEEP_TRACE(j, 3);
+            wt_rows_from_lds<2>(rF, (unsigned)((((long)I * NB) * ld + (long)j * NB) * 8), ld, sXj, 8 * w, l);
+            const int cnt = ntiles - 1 - j;  // tiles j+1 .. ntiles-1
+            pre_l = false;
+            if (cnt > 0) {
+#pragma unroll
+                for (int s = 0; s < 8; ++s) ax.v[s] = sXj[(wr * 16 + fr) * TLD + 8 * fk + s];
+                // column j of L: tile (j+1, j) from the chain workgroup, tiles (t, j), t >= j+2, from the rows of S
+                relay_progress(fnew, CB - 1, [](int) { return 1; }, j + 1, known_new, &L.rnew, fabort, ww, w, l);
+                // X_j is flagged HERE, behind one poll round trip (its stores are ~0.5 us old: a short wait), not behind the
+                // wait for the rows of S: the last of those run late, and the down-date workgroups -- two column blocks from
+                // the end, MFMA-bound -- got block 13 of W 8 us after it existed
+                flag_tile(j);
+                relay_progress(fcol, CB - 1, [CB](int k) { return CB - 2 - k; }, j + 1, known_col, &L.rcol, fabort, ww, w, l);
+                SWEEP_TRACE(j, 1);
+                const double* Lt = F + (long)j * NB + (long)(j + 1) * NB * ld;  // tile (j+1, j); + k * NB * ld
+#pragma unroll
+                for (int r = 0; r < RING; ++r)
+                    if (r < cnt) ring_fill(Lt + (long)r * NB * ld, roff, ring0 + 4096u * r);
+                {   // L_{j+1,j+1}^-1 for the next step, if it is out already
+                    const int seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&L.rdiag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    if (seen >= j + 2 && seen != (1 << 30)) {
+                        ring_fill(Linv + (long)(j + 1) * NB * NB, roffL, ring0 + 4096u * RING_LINV);
+                        pre_l = true;
+                    }
+                }
+                // Everything issued so far has to land before the counted waits of the loop below are meaningful (they
+                // count this panel's LDS-DMA loads only): one full wait.
+                ring_wait(0);
+                Frag8 b[2];
+                ring_frag(b[0], ringw, fr, fk);
+#pragma unroll
+                for (int u = 1; u < MAXT; ++u) {
+                    if (u <= cnt) {
+                        const int k = u - 1;
+                        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): b[k & 1] is here, slot k % RING is free again
+                        asm volatile("" ::: "memory");
+                        if (k + RING < cnt) ring_fill(Lt + (long)(k + RING) * NB * ld, roff, ring0 + 4096u * (k % RING));
+                        d4 a = __builtin_amdgcn_mfma_f64_16x16x4f64(ax.v[0], b[k & 1].v[0], n[u], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (k + 1 < cnt) {
+                            // tiles issued after tile k+1: those still in the ring window behind it
+                            const int behind = (k + RING < cnt ? k + RING : cnt - 1) - (k + 1);
+                            ring_wait(behind < RING - 1 ? behind : RING - 1);
+                            ring_frag(b[(k + 1) & 1], ringw + 512 * ((k + 1) % RING), fr, fk);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int s = 1; s < 8; ++s)
+                            a = __builtin_amdgcn_mfma_f64_16x16x4f64(ax.v[s], b[k & 1].v[s], a, 0, 0, 0);
+                        n[u - 1] = a;
+                    }
+                }
+                mfma_result_guard();
+                SWEEP_TRACE(j, 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) L.sS[(j + 1) & 1][offC + 4 * r * TLD] = -n[0][r];
+                __syncthreads();  // S_{j+1} complete
+            }
+            SWEEP_TRACE(j, 6);
+        }
+    } else
+    for (int j = t0; j <= last; ++j) {
         d4 acc = n[0];
-        newest_panel(j, acc, chain || j - 1 < ntiles - EAGER_TILES, false);  // (the other rows flag their last tiles eagerly, below)
+        // (tile j-1 is flagged here, behind the first load of step j -- unless it is part A's: j == t0 in a part B; the rows of
+        //  W / Ls^-T flag their last tiles eagerly, below)
+        newest_panel(j, acc, j > t0 && (chain || j - 1 < ntiles - EAGER_TILES), false);
         double* sS = L.sS[j & 1];
 #pragma unroll
         for (int r = 0; r < 4; ++r) sS[offC + 4 * r * TLD] = -acc[r];
@@ -2562,7 +2765,7 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
         if (bulk) {
             // A row block of S reads tiles (t, j-1) of the rows t = j+1 .. I-1 only, all of them ahead of it: it waits for
             // exactly those (frow[t] >= j); the others wait for the panel's counter (CB-1-j publications)
-            if (chain) relay_progress_min((XL && local ? flags + fl.frowL : frow) + j + 1, I - 1 - j, j, known_col, &L.rcol, fabort, ww, w, l);
+            if (chain) relay_progress_min((XL && local ? flags + fl.frowL : frow) + j + 1, ntiles - 1 - j, j, known_col, &L.rcol, fabort, ww, w, l);
             else relay_progress(fcol, CB - 1, [CB](int k) { return CB - 2 - k; }, j, known_col, &L.rcol, fabort, ww, w, l);
             const int cnt = tl - j;  // tiles j+1 .. tl
             const double* Lt = F + (long)(j - 1) * NB + (long)(j + 1) * NB * ld;  // tile (j+1, j-1); + k * NB * ld
@@ -2628,10 +2831,12 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
         SWEEP_TRACE_W2(j, 0);
         // (a row block of S stores the tile of its LAST ordinary step behind its feed, see there: nothing between X and the
         // feed that the feed does not need)
-        if (!(chain && j == last))
+        if (!(feeds && j == last))
             wt_rows_from_lds<2>(rF, (unsigned)((((long)I * NB) * ld + (long)j * NB) * 8), ld, sXj, 8 * w, l);
+        else if (XL && local)  // ... but into this XCD's L2 at once: the next row block of S needs it for ITS last update
+            wt_rows_from_lds<2, 0>(rF, (unsigned)((((long)I * NB) * ld + (long)j * NB) * 8), ld, sXj, 8 * w, l);
         SWEEP_TRACE_W2(j, 1);
-        if (chain) {
+        if (feeds) {
             if (j != last) {  // (the last one is made in the feed, behind the request for the newest tile)
 #pragma unroll
                 for (int s = 0; s < 8; ++s)
@@ -2639,7 +2844,7 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
                                                                 sXj[(wc * 16 + fr) * TLD + 8 * fk + s], accD, 0, 0, 0);
                 mfma_result_guard();
             }
-        } else if (j >= ntiles - EAGER_TILES && j <= ntiles - 2) {
+        } else if (!chain && j >= ntiles - EAGER_TILES && j <= ntiles - 2) {
             // The last tiles (but the very last, which is flagged behind the loop) are flagged NOW (1-1.5 us of write-through drain that this row block would spend waiting
             // for the chain's last block anyway), not at the next step's first load as the others: the down-date workgroups
             // got block CB-2 of W only when the chain's last factorisation was through, 4-5 us late, and finished 10 us behind
@@ -2657,7 +2862,7 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
         }
         SWEEP_TRACE(j, 6);
     }
-    if (chain) {
+    if (feeds) {
         // j = I - 1: tile I-1 with all panels but the last goes to the chain workgroup together with -D'.  (Behind the loop, not
         // a pass of it: the loop's back-edge moves all accumulator registers, 0.5 us that sat on the critical cycle
         // L^-1 -> X -> feed -> next factorisation.)
@@ -2693,24 +2898,19 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
         if (last >= 0) {
             const double* sXl = (last & 1) ? L.sP[0] : L.sX;
             const unsigned org = (unsigned)((((long)I * NB) * ld + (long)last * NB) * 8);
-            if (XL && local) {
-                wt_rows_from_lds<2, 0>(rF, org, ld, sXl, 8 * w, l);
-                drain_vmem();
-                int lastw = 0;
-                if (l == 0) lastw = __hip_atomic_fetch_add(&L.pub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 3;
-                if (__builtin_amdgcn_readfirstlane(lastw) && l == 0) l2_flag_st(rflags, fl.frowL + I, last + 1);
-            }
+            // (XL, on the chain workgroup's XCD: stored into the L2 at the end of the last ordinary step and flagged for the
+            //  pollers on this XCD inside the feed step, see newest_panel; here the written-through copy for everybody else)
             wt_rows_from_lds<2>(rF, org, ld, sXl, 8 * w, l);
             flag_tile(last);
         }
     }
-    if (!chain) flag_tile(ntiles - 1);  // (a chain row has flagged its last own tile in its feed step)
+    if (!feeds) flag_tile(ntiles - 1);  // (a feeding row block of S has flagged its last own tile in its feed step)
     if (!chain) {
         if constexpr (FUSED) {
             const int RBW = RT - 2 * CB - 1, zb = CB + RBW;
-            if (I != zb) {  // the vector ops of the step for the rows this workgroup has just finished (see k_sweep)
+            if (I != zb && part != 1) {  // the vector ops of the step for the rows this workgroup has just finished (see k_sweep)
                 __syncthreads();  // every wave has drained this row block's last tile
-                relay_wait_ge(frow + zb, CB, &L.rzb, 1, fabort, ww, w);
+                relay_wait_ge(frow + zb, CB, &L.rzb, 1 << 24, fabort, ww, w);  // (tag above those of a part B's prologue)
                 const long Dp = (long)RBW * NB;
                 const long row0 = (I < zb ? (long)(I - CB) * NB : Dp + (long)(I - zb - 1) * NB) + 8 * w;
                 const double* W = F + (long)ld * ld;
@@ -3211,16 +3411,19 @@ void launch_sweep(unsigned grid, hipStream_t st, const double* G, double* F, dou
     // behind the abort word (`claim`) say so
     // XL (row blocks of S on the chain workgroup's XCD: blocks 8 s, the blocks between them empty)
     const bool xl = home >= 0;
-    unsigned xgrid = 8u * (unsigned)(CB - 1) + 1u;
-    for (unsigned left = grid - (unsigned)CB; left > 0; ++xgrid)  // the other workgroups, skipping the blocks = 0 mod 8
+    // k_sweep_rl's grid: the caller's `grid` workgroups (RT row blocks [+ pairs]) + the parts B of the split row blocks of W
+    // (logical indices RT .. RT + nw - 1, in front of the pairs) + (XL) the parts B of the split row blocks of S
+    const unsigned rgrid = grid + (unsigned)w_split_count(RT, CB);
+    unsigned xgrid = 8u * (unsigned)(CB - 1 + s_split_count(CB, true)) + 1u;
+    for (unsigned left = rgrid - (unsigned)CB; left > 0; ++xgrid)  // the other workgroups, skipping the blocks = 0 mod 8
         if (xgrid % 8u != 0u) --left;
     xgrid += (unsigned)(xl ? home : 0);
     if (sweep_rl_enabled() && CB <= 9) {
         if (xl) k_sweep_rl<N, FUSED, 9, true><<<xgrid, 256, 0, st>>>(G, F, Linv, ld, CB, RT, flags, info, ctr, dd, hs, lenient, home);
-        else k_sweep_rl<N, FUSED, 9, false><<<grid + 1, 256, 0, st>>>(G, F, Linv, ld, CB, RT, flags, info, ctr, dd, hs, lenient, home);
+        else k_sweep_rl<N, FUSED, 9, false><<<rgrid + 1, 256, 0, st>>>(G, F, Linv, ld, CB, RT, flags, info, ctr, dd, hs, lenient, home);
     } else if (sweep_rl_enabled() && CB <= 17) {
         if (xl) k_sweep_rl<N, FUSED, 17, true><<<xgrid, 256, 0, st>>>(G, F, Linv, ld, CB, RT, flags, info, ctr, dd, hs, lenient, home);
-        else k_sweep_rl<N, FUSED, 17, false><<<grid + 1, 256, 0, st>>>(G, F, Linv, ld, CB, RT, flags, info, ctr, dd, hs, lenient, home);
+        else k_sweep_rl<N, FUSED, 17, false><<<rgrid + 1, 256, 0, st>>>(G, F, Linv, ld, CB, RT, flags, info, ctr, dd, hs, lenient, home);
     }
     else  // (a 33-tile row block no longer fits the register file: measured 1280 us against 666 at N = 1024)
         k_sweep<N, FUSED><<<grid, 256, 0, st>>>(G, F, Linv, ld, CB, RT, flags, info, ctr, dd, claim, hs, lenient);
