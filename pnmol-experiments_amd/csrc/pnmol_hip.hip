@@ -2552,59 +2552,21 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
                 __hip_atomic_fetch_add(flags + fl.fcol + l * fl.CBp + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
-    // (1) of a step: the newest panel (j-1) on tile j
-    auto newest_panel = [&](int j, d4& acc, bool flag_previous, bool with_syrk) {
-        SWEEP_TRACE(j, 0);
-        if (j >= 1) {
-            const double* sXp = ((j - 1) & 1) ? L.sP[0] : L.sX;
-#pragma unroll
-            for (int s = 0; s < 8; ++s) ax.v[s] = sXp[(wr * 16 + fr) * TLD + 8 * fk + s];
-            // tile (j, j-1), from the chain workgroup
-            Frag8 b0;
-            if (pre_b0) {  // (on its way since the end of step j-1)
-                SWEEP_TRACE(j, 1);
-                ring_wait(0);
-                ring_frag(b0, ringw + 512 * RING_NEWEST, fr, fk);
-            } else {
-                relay_progress(fnew, CB - 1, [](int) { return 1; }, j, known_new, &L.rnew, fabort, ww, w, l);
-                SWEEP_TRACE(j, 1);
-                frag_ld(b0, F + ((long)j * NB + wc * 16 + fr) * ld + (long)(j - 1) * NB + 8 * fk);
-            }
-            if (with_syrk) {
-                // (the feed) D' -= X_{j-1} X_{j-1}^T, left out of step j-1: its MFMAs are issued behind the request for the
-                // newest tile and in front of its use (pinned), 0.45 us behind a 0.45 us load on the cycle
-                // L^-1 -> X -> feed -> chain
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int s = 0; s < 8; ++s)
-                    accD = __builtin_amdgcn_mfma_f64_16x16x4f64(ax.v[s], sXp[(wc * 16 + fr) * TLD + 8 * fk + s], accD, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            SWEEP_TRACE_VM(j, 7);
-            if (with_syrk && XL && local) {
-                // (the feed step of a row block of S) tile (I, I-2), stored into the L2 at the end of the last ordinary step,
-                // has drained when the newest tile is here: flag it for the next row block now, not behind the feed
-                drain_vmem();
-                int lastw = 0;
-                if (l == 0) lastw = __hip_atomic_fetch_add(&L.pub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 3;
-                if (__builtin_amdgcn_readfirstlane(lastw) && l == 0 && I >= 2) l2_flag_st(rflags, fl.frowL + I, I - 1);
-            }
-#pragma unroll
-            for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ax.v[s], b0.v[s], acc, 0, 0, 0);
-            mfma_result_guard();
-            if (flag_previous) flag_tile(j - 1);  // (b0 has arrived: so have the stores of tile j-1, issued before its load)
-        }
-    };
     if (part == 2) {
-        // Part B of a split row block of S.  Columns k = 0 .. t0-2: X_{I,k} comes from part A (tile (I, k) of F, same XCD),
-        // panel k goes onto ALL own tiles t0 .. I-1 (slots stay put) and onto D'.  Then X_{I,t0-1} is fetched into the LDS
-        // buffer the first ordinary step (j = t0) takes its "previous X" from, and that step finds everything as if this
-        // workgroup had run the steps before it.
+        // Part B of a split row block.  Columns k = 0 .. t0-1: X_{I,k} comes from part A (tile (I, k) of F), panel k goes onto
+        // ALL own tiles t0 .. ntiles-1 (the slots stay put) and, for a row block of S, onto D': the first step below (j = t0)
+        // finds its tiles as if this workgroup had run the steps before it.
         const int* fsrc = (XL && local) ? flags + fl.frowL : frow;
-        for (int k = 0; k + (chain ? 1 : 0) < t0; ++k) {  // (a part B of W: all panels k < t0, see the eager loop below)
+        for (int k = 0; k < t0; ++k) {
             if (chain) {
-                relay_progress_min(fsrc + t0, I - t0 + 1, k + 1, known_col, &L.rcol, fabort, ww, w, l);  // rows t0 .. I: tile k out
+                if (k + 1 < t0) {
+                    relay_progress_min(fsrc + t0, I - t0 + 1, k + 1, known_col, &L.rcol, fabort, ww, w, l);  // rows t0 .. I: tile k out
+                } else {  // (k = t0-1: tile (t0, t0-1) is the chain workgroup's; rows t0+1 .. I, part A among them, have the rest)
+                    relay_progress(fnew, CB - 1, [](int) { return 1; }, t0, known_new, &L.rnew, fabort, ww, w, l);
+                    relay_progress_min(fsrc + t0 + 1, I - t0, t0, known_col, &L.rcol, fabort, ww, w, l);
+                }
             } else {  // (a row block of W: all rows of S have published tile k; part A has published tile (I, k))
+                relay_progress(fnew, CB - 1, [](int) { return 1; }, k + 1, known_new, &L.rnew, fabort, ww, w, l);
                 relay_progress(fcol, CB - 1, [CB](int q) { return CB - 2 - q; }, k + 1, known_col, &L.rcol, fabort, ww, w, l);
                 relay_wait_ge(frow + I, k + 1, &L.rzb, k + 1, fabort, ww, w);
             }
@@ -2632,182 +2594,24 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
             }
             mfma_result_guard();
         }
-        if (chain) {
-        relay_wait_ge(fsrc + I, t0, &L.rzb, t0, fabort, ww, w);  // part A has published tile t0 - 1 (own relay word: the
-                                                                 // range polls above and below keep their meaning)
-        double* sXp = ((t0 - 1) & 1) ? L.sP[0] : L.sX;
-        tile_g2s(F + ((long)I * NB) * ld + (long)(t0 - 1) * NB, ld, sXp, tid);
-        __syncthreads();
-#pragma unroll
-            for (int s = 0; s < 8; ++s)
-                accD = __builtin_amdgcn_mfma_f64_16x16x4f64(sXp[(wr * 16 + fr) * TLD + 8 * fk + s],
-                                                            sXp[(wc * 16 + fr) * TLD + 8 * fk + s], accD, 0, 0, 0);
-            mfma_result_guard();
-        }
     }
-    // Rows of W, the r^T block, rows of Ls^-T: EAGER right-looking steps.  These row blocks lag behind the chain workgroup, so
-    // when X_j exists the whole column j of L -- tile (j+1, j) from the chain workgroup, tiles (t, j) of the later rows of
-    // S -- is out or about to be: panel j goes onto ALL remaining tiles at once, tile j+1 included, and the next step starts
-    // with a finished S_{j+1}.  Against the scheme of the rows of S below (newest panel j-1 on tile j, panel j-1 on the rest,
-    // then X_j) a step loses one poll, one dependent tile load, one 8-MFMA product with its LDS round trip -- 1.2-1.5 us of
-    // the ~4.2 us a step costs beside its tile updates -- and X_j is flagged right behind its stores instead of a step later.
-    // Same operations on the same operands in the same order per tile: bit-identical results.
-    if (!chain) {
+    // EAGER right-looking steps (all row blocks).  When X_j exists, the whole column j of L -- tile (j+1, j) from the chain
+    // workgroup, tiles (t, j) of the later rows of S -- is out or about to be: panel j goes onto ALL remaining tiles at once,
+    // tile j+1 included, and the next step starts with a finished S_{j+1}.  Round 2's step (panel j-1 onto tile j "newest
+    // panel", panel j-1 onto the rest, then X_j) had one more poll, one more dependent tile load and one more 8-MFMA product
+    // with its LDS round trip and barrier per step: ~4.2 us beside the tile updates for a row of W, 5.5-6.8 us for a row of S
+    // whatever it had left to update -- and the rows of S, each one step of that length per chain block, set the period of
+    // the chain workgroup (6.6 us against the 4.5 it needs; profiles/r03_microbench/sweep_timeline_e_s_row7_trace.log).
+    // Same operations on the same operands in the same order per tile: the results are bit-identical to round 2's.
+    // A row block of S that feeds ends with its feed INSIDE its last step: panel I-2 onto tile I-1 is that step's bulk.
+    const bool lastlocal = feeds && XL && local;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) L.sS[t0 & 1][offC + 4 * r * TLD] = -n[0][r];
-        __syncthreads();
-        bool pre_l = false;
-        for (int j = t0; j <= last; ++j) {
-            const double* sS = L.sS[j & 1];
-            SWEEP_TRACE(j, 0);
-            relay_progress(fdiag, CB, [](int) { return 1; }, j + 1, known_diag, &L.rdiag, fabort, ww, w, l);
-            SWEEP_TRACE(j, 5);
-            Frag8 bl;
-            if (pre_l) {
-                ring_wait(0);
-                ring_frag(bl, ringw + 512 * RING_LINV, fr, fk);
-            } else {
-                frag_ld(bl, Linv + (long)j * NB * NB + (wc * 16 + fr) * NB + 8 * fk);
-            }
-            d4 x = {0, 0, 0, 0};
-#pragma unroll
-            for (int s = 0; s < 8; ++s)
-                x = __builtin_amdgcn_mfma_f64_16x16x4f64(sS[(wr * 16 + fr) * TLD + 8 * fk + s], bl.v[s], x, 0, 0, 0);
-            double* sXj = (j & 1) ? L.sP[0] : L.sX;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sXj[offC + 4 * r * TLD] = x[r];
-            __syncthreads();  // X_j complete
-            SWEEP_TRACE(j, 3);
-            wt_rows_from_lds<2>(rF, (unsigned)((((long)I * NB) * ld + (long)j * NB) * 8), ld, sXj, 8 * w, l);
-            const int cnt = ntiles - 1 - j;  // tiles j+1 .. ntiles-1
-            pre_l = false;
-            if (cnt > 0) {
-#pragma unroll
-                for (int s = 0; s < 8; ++s) ax.v[s] = sXj[(wr * 16 + fr) * TLD + 8 * fk + s];
-                // column j of L: tile (j+1, j) from the chain workgroup, tiles (t, j), t >= j+2, from the rows of S
-                relay_progress(fnew, CB - 1, [](int) { return 1; }, j + 1, known_new, &L.rnew, fabort, ww, w, l);
-                // X_j is flagged HERE, behind one poll round trip (its stores are ~0.5 us old: a short wait), not behind the
-                // wait for the rows of S: the last of those run late, and the down-date workgroups -- two column blocks from
-                // the end, MFMA-bound -- got block 13 of W 8 us after it existed
-                flag_tile(j);
-                relay_progress(fcol, CB - 1, [CB](int k) { return CB - 2 - k; }, j + 1, known_col, &L.rcol, fabort, ww, w, l);
-                SWEEP_TRACE(j, 1);
-                const double* Lt = F + (long)j * NB + (long)(j + 1) * NB * ld;  // tile (j+1, j); + k * NB * ld
-#pragma unroll
-                for (int r = 0; r < RING; ++r)
-                    if (r < cnt) ring_fill(Lt + (long)r * NB * ld, roff, ring0 + 4096u * r);
-                {   // L_{j+1,j+1}^-1 for the next step, if it is out already
-                    const int seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&L.rdiag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                    if (seen >= j + 2 && seen != (1 << 30)) {
-                        ring_fill(Linv + (long)(j + 1) * NB * NB, roffL, ring0 + 4096u * RING_LINV);
-                        pre_l = true;
-                    }
-                }
-                // Everything issued so far has to land before the counted waits of the loop below are meaningful (they
-                // count this panel's LDS-DMA loads only): one full wait.
-                ring_wait(0);
-                Frag8 b[2];
-                ring_frag(b[0], ringw, fr, fk);
-#pragma unroll
-                for (int u = 1; u < MAXT; ++u) {
-                    if (u <= cnt) {
-                        const int k = u - 1;
-                        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): b[k & 1] is here, slot k % RING is free again
-                        asm volatile("" ::: "memory");
-                        if (k + RING < cnt) ring_fill(Lt + (long)(k + RING) * NB * ld, roff, ring0 + 4096u * (k % RING));
-                        d4 a = __builtin_amdgcn_mfma_f64_16x16x4f64(ax.v[0], b[k & 1].v[0], n[u], 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (k + 1 < cnt) {
-                            // tiles issued after tile k+1: those still in the ring window behind it
-                            const int behind = (k + RING < cnt ? k + RING : cnt - 1) - (k + 1);
-                            ring_wait(behind < RING - 1 ? behind : RING - 1);
-                            ring_frag(b[(k + 1) & 1], ringw + 512 * ((k + 1) % RING), fr, fk);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int s = 1; s < 8; ++s)
-                            a = __builtin_amdgcn_mfma_f64_16x16x4f64(ax.v[s], b[k & 1].v[s], a, 0, 0, 0);
-                        n[u - 1] = a;
-                    }
-                }
-                mfma_result_guard();
-                SWEEP_TRACE(j, 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) L.sS[(j + 1) & 1][offC + 4 * r * TLD] = -n[0][r];
-                __syncthreads();  // S_{j+1} complete
-            }
-            SWEEP_TRACE(j, 6);
-        }
-    } else
+    for (int r = 0; r < 4; ++r) L.sS[t0 & 1][offC + 4 * r * TLD] = -n[0][r];
+    __syncthreads();
+    bool pre_l = false;
     for (int j = t0; j <= last; ++j) {
-        d4 acc = n[0];
-        // (tile j-1 is flagged here, behind the first load of step j -- unless it is part A's: j == t0 in a part B; the rows of
-        //  W / Ls^-T flag their last tiles eagerly, below)
-        newest_panel(j, acc, j > t0 && (chain || j - 1 < ntiles - EAGER_TILES), false);
-        double* sS = L.sS[j & 1];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sS[offC + 4 * r * TLD] = -acc[r];
-        __syncthreads();  // S_j complete
-        SWEEP_TRACE(j, 2);
-        bool pre_l = false;
-        {
-            const int seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&L.rdiag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-            if (seen >= j + 1 && seen != (1 << 30)) {
-                ring_fill(Linv + (long)j * NB * NB, roffL, ring0 + 4096u * RING_LINV);
-                pre_l = true;
-            }
-        }
-        const int tl = ntiles - 1;
-        const bool bulk = j >= 1 && j + 1 < ntiles;
-        // (3) panel j-1 on the tiles j+1 .. ntiles-1; the slots move down by one.  Done BEFORE the wait for L_jj^-1: its
-        // operands, tiles (t, j-1), were published a whole step ago, and a row block of S near the diagonal -- the next ones
-        // to feed the chain workgroup -- would otherwise do this work between L_jj^-1 and its feed.
-        if (bulk) {
-            // A row block of S reads tiles (t, j-1) of the rows t = j+1 .. I-1 only, all of them ahead of it: it waits for
-            // exactly those (frow[t] >= j); the others wait for the panel's counter (CB-1-j publications)
-            if (chain) relay_progress_min((XL && local ? flags + fl.frowL : frow) + j + 1, ntiles - 1 - j, j, known_col, &L.rcol, fabort, ww, w, l);
-            else relay_progress(fcol, CB - 1, [CB](int k) { return CB - 2 - k; }, j, known_col, &L.rcol, fabort, ww, w, l);
-            const int cnt = tl - j;  // tiles j+1 .. tl
-            const double* Lt = F + (long)(j - 1) * NB + (long)(j + 1) * NB * ld;  // tile (j+1, j-1); + k * NB * ld
-#pragma unroll
-            for (int r = 0; r < RING; ++r)
-                if (r < cnt) ring_fill(Lt + (long)r * NB * ld, roff, ring0 + 4096u * r);
-            // The fragments of tile k+1 are read from the ring right behind the FIRST of the eight dependent MFMAs of tile k
-            // (pinned there: the compiler's in-order lgkmcnt bookkeeping would otherwise make tile k's MFMAs wait for them) and
-            // land while the other seven run: with one wave per SIMD nothing else hides the ds_read latency.
-            Frag8 b[2];
-            ring_wait(cnt - 1 < RING - 1 ? cnt - 1 : RING - 1);
-            ring_frag(b[0], ringw, fr, fk);
-#pragma unroll
-            for (int u = 1; u < MAXT; ++u) {
-                if (j + u <= tl) {
-                    const int k = u - 1;
-                    // b[k & 1] is here: slot k % RING is free again.  (The builtin, not an asm statement: the compiler then
-                    // knows that nothing older is pending and does not make this tile's MFMAs wait for the next reads.)
-                    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-                    asm volatile("" ::: "memory");
-                    if (k + RING < cnt) ring_fill(Lt + (long)(k + RING) * NB * ld, roff, ring0 + 4096u * (k % RING));
-                    d4 a = __builtin_amdgcn_mfma_f64_16x16x4f64(ax.v[0], b[k & 1].v[0], n[u], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (k + 1 < cnt) {
-                        const int behind = cnt - 2 - k;  // tiles issued after tile k+1 (capped by the ring)
-                        ring_wait(behind < RING - 1 ? behind : RING - 1);
-                        ring_frag(b[(k + 1) & 1], ringw + 512 * ((k + 1) % RING), fr, fk);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int s = 1; s < 8; ++s)
-                        a = __builtin_amdgcn_mfma_f64_16x16x4f64(ax.v[s], b[k & 1].v[s], a, 0, 0, 0);
-                    n[u - 1] = a;
-                }
-            }
-        } else if (j == 0) {
-#pragma unroll
-            for (int u = 1; u < MAXT; ++u)
-                if (u < ntiles) n[u - 1] = n[u];
-        }
-        SWEEP_TRACE(j, 4);
-        // (2) X_j = S_j L_jj^-T
+        const double* sS = L.sS[j & 1];
+        SWEEP_TRACE(j, 0);
         relay_progress(fdiag, CB, [](int) { return 1; }, j + 1, known_diag, &L.rdiag, fabort, ww, w, l);
         SWEEP_TRACE(j, 5);
         Frag8 bl;
@@ -2825,53 +2629,101 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
 #pragma unroll
         for (int r = 0; r < 4; ++r) sXj[offC + 4 * r * TLD] = x[r];
         __syncthreads();  // X_j complete
-        // every wave publishes a quarter of the tile (two full 1-KB store instructions): one publishing wave's eight
-        // stores, competing with the other waves' operand loads, took 2.3-3.8 us to issue, and everybody waited for that
-        // wave at the next barrier
-        SWEEP_TRACE_W2(j, 0);
-        // (a row block of S stores the tile of its LAST ordinary step behind its feed, see there: nothing between X and the
-        // feed that the feed does not need)
-        if (!(feeds && j == last))
-            wt_rows_from_lds<2>(rF, (unsigned)((((long)I * NB) * ld + (long)j * NB) * 8), ld, sXj, 8 * w, l);
-        else if (XL && local)  // ... but into this XCD's L2 at once: the next row block of S needs it for ITS last update
-            wt_rows_from_lds<2, 0>(rF, (unsigned)((((long)I * NB) * ld + (long)j * NB) * 8), ld, sXj, 8 * w, l);
-        SWEEP_TRACE_W2(j, 1);
-        if (feeds) {
-            if (j != last) {  // (the last one is made in the feed, behind the request for the newest tile)
-#pragma unroll
-                for (int s = 0; s < 8; ++s)
-                    accD = __builtin_amdgcn_mfma_f64_16x16x4f64(sXj[(wr * 16 + fr) * TLD + 8 * fk + s],
-                                                                sXj[(wc * 16 + fr) * TLD + 8 * fk + s], accD, 0, 0, 0);
-                mfma_result_guard();
-            }
-        } else if (!chain && j >= ntiles - EAGER_TILES && j <= ntiles - 2) {
-            // The last tiles (but the very last, which is flagged behind the loop) are flagged NOW (1-1.5 us of write-through drain that this row block would spend waiting
-            // for the chain's last block anyway), not at the next step's first load as the others: the down-date workgroups
-            // got block CB-2 of W only when the chain's last factorisation was through, 4-5 us late, and finished 10 us behind
-            // the sweep.
-            flag_tile(j);
-        }
         SWEEP_TRACE(j, 3);
-        pre_b0 = false;
-        if (j + 1 < ntiles) {
-            const int seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&L.rnew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-            if (seen >= j + 1 && seen != (1 << 30)) {
-                ring_fill(F + (long)(j + 1) * NB * ld + (long)j * NB, roff, ring0 + 4096u * RING_NEWEST);
-                pre_b0 = true;
+        // every wave publishes a quarter of the tile (two full 1-KB store instructions).  The last ordinary tile of a feeding
+        // row block on the chain workgroup's XCD goes into that XCD's L2 only (the next row block of S needs it for ITS last
+        // step); its written-through copy follows behind the feed
+        const bool llast = lastlocal && j == last;
+        const unsigned orgX = (unsigned)((((long)I * NB) * ld + (long)j * NB) * 8);
+        if (llast) wt_rows_from_lds<2, 0>(rF, orgX, ld, sXj, 8 * w, l);
+        else wt_rows_from_lds<2>(rF, orgX, ld, sXj, 8 * w, l);
+        if (feeds) {  // D' -= X_j X_j^T
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                accD = __builtin_amdgcn_mfma_f64_16x16x4f64(sXj[(wr * 16 + fr) * TLD + 8 * fk + s],
+                                                            sXj[(wc * 16 + fr) * TLD + 8 * fk + s], accD, 0, 0, 0);
+            mfma_result_guard();
+        }
+        const int cnt = ntiles - 1 - j;  // tiles j+1 .. ntiles-1
+        pre_l = false;
+        if (cnt > 0) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) ax.v[s] = sXj[(wr * 16 + fr) * TLD + 8 * fk + s];
+            // column j of L: tile (j+1, j) from the chain workgroup ...
+            relay_progress(fnew, CB - 1, [](int) { return 1; }, j + 1, known_new, &L.rnew, fabort, ww, w, l);
+            // X_j is flagged HERE, behind one poll round trip (its stores are ~0.5 us old: a short wait), not behind the wait
+            // for the other rows of S
+            if (llast) {
+                drain_vmem();
+                int lastw = 0;
+                if (l == 0) lastw = __hip_atomic_fetch_add(&L.pub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 3;
+                if (__builtin_amdgcn_readfirstlane(lastw) && l == 0) l2_flag_st(rflags, fl.frowL + I, j + 1);
+            } else {
+                flag_tile(j);
+            }
+            // ... tiles (t, j), t >= j+2, from the rows of S: a row block of S reads those of the rows j+2 .. ntiles-1 only and
+            // waits for exactly them, the others for the column's counter
+            if (chain) {
+                if (cnt > 1)
+                    relay_progress_min((XL && local ? flags + fl.frowL : frow) + j + 2, cnt - 1, j + 1, known_col, &L.rcol, fabort, ww, w, l);
+            } else {
+                relay_progress(fcol, CB - 1, [CB](int k) { return CB - 2 - k; }, j + 1, known_col, &L.rcol, fabort, ww, w, l);
+            }
+            SWEEP_TRACE(j, 1);
+            const double* Lt = F + (long)j * NB + (long)(j + 1) * NB * ld;  // tile (j+1, j); + k * NB * ld
+#pragma unroll
+            for (int r = 0; r < RING; ++r)
+                if (r < cnt) ring_fill(Lt + (long)r * NB * ld, roff, ring0 + 4096u * r);
+            if (!chain) {  // L_{j+1,j+1}^-1 for the next step, if it is out already (the rows that lag behind the chain)
+                const int seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&L.rdiag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (seen >= j + 2 && seen != (1 << 30)) {
+                    ring_fill(Linv + (long)(j + 1) * NB * NB, roffL, ring0 + 4096u * RING_LINV);
+                    pre_l = true;
+                }
+            }
+            // Everything issued so far has to land before the counted waits of the loop below are meaningful (they count
+            // this panel's LDS-DMA loads only): one full wait.
+            ring_wait(0);
+            Frag8 b[2];
+            ring_frag(b[0], ringw, fr, fk);
+#pragma unroll
+            for (int u = 1; u < MAXT; ++u) {
+                if (u <= cnt) {
+                    const int k = u - 1;
+                    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): b[k & 1] is here, slot k % RING is free again
+                    asm volatile("" ::: "memory");
+                    if (k + RING < cnt) ring_fill(Lt + (long)(k + RING) * NB * ld, roff, ring0 + 4096u * (k % RING));
+                    d4 a = __builtin_amdgcn_mfma_f64_16x16x4f64(ax.v[0], b[k & 1].v[0], n[u], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (k + 1 < cnt) {
+                        // tiles issued after tile k+1: those still in the ring window behind it
+                        const int behind = (k + RING < cnt ? k + RING : cnt - 1) - (k + 1);
+                        ring_wait(behind < RING - 1 ? behind : RING - 1);
+                        ring_frag(b[(k + 1) & 1], ringw + 512 * ((k + 1) % RING), fr, fk);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int s = 1; s < 8; ++s)
+                        a = __builtin_amdgcn_mfma_f64_16x16x4f64(ax.v[s], b[k & 1].v[s], a, 0, 0, 0);
+                    n[u - 1] = a;
+                }
+            }
+            mfma_result_guard();
+            SWEEP_TRACE(j, 4);
+            if (!(feeds && j == last)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) L.sS[(j + 1) & 1][offC + 4 * r * TLD] = -n[0][r];
+                __syncthreads();  // S_{j+1} complete
             }
         }
         SWEEP_TRACE(j, 6);
     }
     if (feeds) {
-        // j = I - 1: tile I-1 with all panels but the last goes to the chain workgroup together with -D'.  (Behind the loop, not
-        // a pass of it: the loop's back-edge moves all accumulator registers, 0.5 us that sat on the critical cycle
-        // L^-1 -> X -> feed -> next factorisation.)
+        // slot 0 is tile I-1 with every panel but the last: it goes to the chain workgroup together with -D'
         const int j = I - 1;
-        d4 acc = n[0];
-        newest_panel(j, acc, false, true);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            L.sS[0][offC + 4 * r * TLD] = -acc[r];
+            L.sS[0][offC + 4 * r * TLD] = -n[0][r];
             L.sS[1][offC + 4 * r * TLD] = accD[r];
         }
         __syncthreads();
@@ -2892,19 +2744,14 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
         }
         SWEEP_TRACE(j, 4);
         SWEEP_STAMP(1);
-        // Tile (I, I-2), X of the last ordinary step (still in its LDS buffer: the feed used sS only), goes out now: the next
-        // row block of S needs it for its last-but-one update one chain period from now, the others later.  Into the L2
-        // first, flagged for the pollers on this XCD (frowL) as soon as that has drained; then written through.
-        if (last >= 0) {
+        // (on the chain workgroup's XCD) the written-through copy of tile (I, I-2) for everybody else, and its flags
+        if (last >= 0 && lastlocal) {
             const double* sXl = (last & 1) ? L.sP[0] : L.sX;
-            const unsigned org = (unsigned)((((long)I * NB) * ld + (long)last * NB) * 8);
-            // (XL, on the chain workgroup's XCD: stored into the L2 at the end of the last ordinary step and flagged for the
-            //  pollers on this XCD inside the feed step, see newest_panel; here the written-through copy for everybody else)
-            wt_rows_from_lds<2>(rF, org, ld, sXl, 8 * w, l);
+            wt_rows_from_lds<2>(rF, (unsigned)((((long)I * NB) * ld + (long)last * NB) * 8), ld, sXl, 8 * w, l);
             flag_tile(last);
         }
     }
-    if (!feeds) flag_tile(ntiles - 1);  // (a feeding row block of S has flagged its last own tile in its feed step)
+    if (!feeds) flag_tile(ntiles - 1);  // (a feeding row block of S has flagged its last own tile in or behind its feed)
     if (!chain) {
         if constexpr (FUSED) {
             const int RBW = RT - 2 * CB - 1, zb = CB + RBW;
