@@ -1509,12 +1509,101 @@ __device__ __forceinline__ void sweep_downdate_body(SweepLds& L, const DowndateA
         return next;
     };
     if constexpr (SHORT_LAST) {  // (k_sweep_rl; the large problems' k_sweep keeps the plain loop below)
+        // Round 3: every WAVE follows the row flags by itself (its fragments come straight from global memory: nothing in
+        // this loop is shared between the waves), so a column block costs no workgroup barrier; and the flags of block
+        // j+1 are polled -- one non-blocking load -- at the top of block j and looked at two k-steps into its MFMAs, so the
+        // fragments of block j+1 are in flight under the other six.  Round 2's loop refreshed its knowledge of the flags
+        // only when it had to wait, i.e. it re-synchronised (two barriers and a poll round trip, 0.56 us) and then loaded
+        // with nothing to hide the latency behind on every block once it lagged behind the sweep -- which, 72 MFMAs per
+        // block at the one-wave-per-SIMD rate against a chain period of 4.9 us, is always (profiles/r03_microbench).
+        (void)panel;
+        (void)wait_for;
+        // (Only wave 0 touches the flags in memory -- a flag word is served at the memory side, ~12 ns per poll per address,
+        // and 64 waves polling each word made the rows of W themselves 10 us slower -- and relays what it has seen through
+        // one LDS word, L.seen[0]: the number of column blocks known to be complete, monotone.)
+        bool wdead = false;
+        int* relay = &L.seen[0];
+        auto poll_min = [&]() {  // wave 0: smallest published column count over the 2 N row blocks of W this pair reads
+            int v = 1 << 30;
+            if (l < 2 * N) {
+                const int a = l >> 1, tile = (l & 1) ? K : J;
+                v = flag_ld(frow + RBS + a * T32 + tile);
+            }
+            return v;
+        };
+        auto reduce_min = [&](int v) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+            return v;
+        };
+        auto publish = [&](int v) {  // wave 0
+            if (l == 0) __hip_atomic_store(relay, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        auto known = [&]() { return __hip_atomic_load(relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+        auto wave_wait = [&](int j) {
+            if (wdead) return;
+            if (w == 0) {
+                for (int spins = 0;; ++spins) {
+                    const int v = reduce_min(poll_min());
+                    if (v > j) {
+                        publish(v);
+                        return;
+                    }
+                    if (spins > SWEEP_SPIN_LIMIT || ((spins & 63) == 63 && flag_ld(fabort))) {
+                        wdead = true;
+                        flag_st(fabort, 1);
+                        publish(1 << 30);
+                        return;
+                    }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            } else {
+                int v;
+                while ((v = known()) <= j) __builtin_amdgcn_s_sleep(2);
+                if (v == (1 << 30)) wdead = true;
+            }
+        };
+        // one column block: fragments in (fa, fb); those of block j+1 go to (na, nb) if its flags are up
+        auto block = [&](int j, bool have, Frag8 (&fa)[N], Frag8 (&fb)[N], Frag8 (&na)[N], Frag8 (&nb)[N]) {
+            DD_TRACE(j, 0);
+            if (!have) {
+                wave_wait(j);
+                DD_TRACE(j, 1);
+                load_panel(j, fa, fb);
+            }
+            const int pv = (w == 0 && j + 1 < CB) ? poll_min() : 0;  // (wave 0: requested now, looked at below)
+            const int smax = (j + 1 == CB && dd.last_ksteps > 0) ? dd.last_ksteps : 8;
+            bool next = false;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                if (s == 2) {
+                    if (w == 0 && j + 1 < CB && !wdead) {
+                        const int v = reduce_min(pv);
+                        if (v > known()) publish(v);
+                    }
+                    const int kv = known();
+                    next = (j + 1 < CB) && !wdead && kv > j + 1 && kv != (1 << 30);
+                    if (next) load_panel(j + 1, na, nb);
+                }
+                if (s < smax) {
+#pragma unroll
+                    for (int a = 0; a < N; ++a)
+#pragma unroll
+                        for (int b = 0; b < N; ++b)
+                            acc[a][b] = AccOf<PT>::mfma_neg(fa[a].v[s], fb[b].v[s], acc[a][b]);
+                }
+            }
+            DD_TRACE(j, 2);
+            return next;
+        };
         Frag8 fa0[N], fb0[N], fa1[N], fb1[N];
-        bool loaded = false;
+        bool have = false;
         for (int j = 0; j < CB; j += 2) {
-            loaded = panel(j, loaded, fa0, fb0, fa1, fb1);
-            if (j + 1 < CB) loaded = panel(j + 1, loaded, fa1, fb1, fa0, fb0);
+            have = block(j, have, fa0, fb0, fa1, fb1);
+            if (j + 1 < CB) have = block(j + 1, have, fa1, fb1, fa0, fb0);
         }
+        if (wdead && l == 0) atomicMin(info, -2);
+        __syncthreads();  // (the epilogue's staging buffers are per wave, but L.dead / the vector-op tail below are shared)
     } else {
         for (int j = 0; j < CB; ++j) {
             wait_for(j);
@@ -2434,7 +2523,7 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
         I -= nwsplit;                   // (the down-date pairs: logical indices RT ..)
         if constexpr (FUSED) {
             if (tid == 0) {
-                L.dead = 0;
+                L.dead = 0, L.seen[0] = 0;  // (seen[0]: column blocks of W wave 0 has seen complete, see the down-date loop)
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
             __syncthreads();
