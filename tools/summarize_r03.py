@@ -1,12 +1,16 @@
 """Summarise a tools_prof_r03.sh output directory (gpurun_out/<tag>/) into profiles/<name>_summary.md:
 kernel durations (--kernel-trace --stats), HBM bytes (separate --pmc FETCH_SIZE / WRITE_SIZE passes) and the MFMA
-counters (one more --pmc pass).  usage: tools_summarize_r02.py <tag> <name> <steps> [--traffic-json]"""
+counters (one more --pmc pass).  usage: tools/summarize_r03.py <tag> <name> <steps> [--traffic-json] [--nsteps N]
+(N: filter steps the profiled command executed in all, when it is not bench.py's 2 + 2 * steps: the VERDICT of round 2 found a
+summary that divided by the wrong count)"""
 import csv, glob, sys, collections, json
 tag, name, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
 base = f"gpurun_out/{tag}"
 def short(n): return n.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
 stats = list(csv.DictReader(open(glob.glob(f"{base}/trace/*/*kernel_stats.csv")[0])))
-nsteps = 2 + 2 * steps              # warm-up + rehearsal (prepare_steps) + timed
+nsteps = 2 + 2 * steps              # bench.py: warm-up + rehearsal (prepare_steps) + timed
+if "--nsteps" in sys.argv:
+    nsteps = int(sys.argv[sys.argv.index("--nsteps") + 1])
 def counters(kind):
     acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
     for r in csv.DictReader(open(glob.glob(f"{base}/pmc_{kind}/*/*counter_collection.csv")[0])):
