@@ -2747,7 +2747,7 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
                 int lastw = 0;
                 if (l == 0) lastw = __hip_atomic_fetch_add(&L.pub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 3;
                 if (__builtin_amdgcn_readfirstlane(lastw) && l == 0) l2_flag_st(rflags, fl.frowL + I, j + 1);
-            } else {
+            } else if (chain) {
                 flag_tile(j);
             }
             // ... tiles (t, j), t >= j+2, from the rows of S: a row block of S reads those of the rows j+2 .. ntiles-1 only and
@@ -2771,8 +2771,12 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
                 }
             }
             // Everything issued so far has to land before the counted waits of the loop below are meaningful (they count
-            // this panel's LDS-DMA loads only): one full wait.
-            ring_wait(0);
+            // this panel's LDS-DMA loads only): one full wait.  A row block of W / Ls^-T flags X_j on THIS wait -- the
+            // write-through drain of its stores (~0.5 us) and the latency of the first operand tiles overlap instead of
+            // following each other, 17 times per launch in the workgroups the sweep waits for (the column's tiles are
+            // nearly always out when these rows get here, so the flag is not held up by the wait above).
+            if (!chain) flag_tile(j);
+            else ring_wait(0);
             Frag8 b[2];
             ring_frag(b[0], ringw, fr, fk);
 #pragma unroll
