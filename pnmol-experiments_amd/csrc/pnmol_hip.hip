@@ -1435,6 +1435,13 @@ __device__ __forceinline__ void sweep_downdate_body(SweepLds& L, const DowndateA
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 acc[a][b][r] = Ppred[((long)a * dd.dp + J * NB + qr * 16 + AccOf<PT>::row(fk, r)) * Dp + (long)b * dd.dp + K * NB + qc * 16 + fr];
+    // K[j,k] of the fused predict in the epilogue, requested NOW: asked for behind the last column block, its two levels of
+    // cache misses were 1-2 us of the sweep's tail in every pair (the epilogue is on the step's critical path)
+    acc_t kjk = {0, 0, 0, 0};
+    if (dd.Pnext) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) kjk[r] = (PT)dd.Kg[(long)(J * NB + qr * 16 + AccOf<PT>::row(fk, r)) * dd.dp + K * NB + qc * 16 + fr];
+    }
     int avail = 0;  // column blocks of W known to be complete for all 2 N row blocks
     // wait until column block j is there (all threads)
     auto wait_for = [&](int j) {
@@ -1624,13 +1631,13 @@ __device__ __forceinline__ void sweep_downdate_body(SweepLds& L, const DowndateA
     // step's predicted covariance
     PT* stg = reinterpret_cast<PT*>(L.sP[w]);
     const bool write_p = dd.Pnext == nullptr || (slot + 1 == *dd.last_ctr);
-    auto put_block = [&](PT* dst, const acc_t& v, long row0, long col0) {
+    auto put_block = [&](PT* dst, const acc_t& v, long row0, long col0, bool mirror) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             dst[(row0 + AccOf<PT>::row(fk, r)) * Dp + col0 + fr] = v[r];
-            if (J != K) stg[AccOf<PT>::row(fk, r) * 17 + fr] = v[r];
+            if (J != K && mirror) stg[AccOf<PT>::row(fk, r) * 17 + fr] = v[r];
         }
-        if (J != K) {
+        if (J != K && mirror) {
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int r = 0; r < 4; ++r)  // stg[i][c] = tile(i, c); mirror row c (= fk + 4 r) holds tile(:, c)
@@ -1648,13 +1655,10 @@ __device__ __forceinline__ void sweep_downdate_body(SweepLds& L, const DowndateA
         }
         if (write_p) {
 #pragma unroll
-            for (int b = 0; b < N; ++b) put_block(static_cast<PT*>(dd.Pout), acc[a][b], row0, (long)b * dd.dp + K * NB + qc * 16);
+            for (int b = 0; b < N; ++b) put_block(static_cast<PT*>(dd.Pout), acc[a][b], row0, (long)b * dd.dp + K * NB + qc * 16, true);
         }
     }
     if (dd.Pnext) {  // P-' = A1 X A1^T + Q1 K[j,k] per point pair, X = the n x n entries this lane holds
-        acc_t kjk;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) kjk[r] = (PT)dd.Kg[(long)(J * NB + qr * 16 + AccOf<PT>::row(fk, r)) * dd.dp + K * NB + qc * 16 + fr];
         acc_t T[N][N];
 #pragma unroll
         for (int a = 0; a < N; ++a)
@@ -1672,7 +1676,11 @@ __device__ __forceinline__ void sweep_downdate_body(SweepLds& L, const DowndateA
                 acc_t pn = (PT)dd.Q1[a * MAXN + b] * kjk;
 #pragma unroll
                 for (int e = 0; e < N; ++e) pn += T[a][e] * (PT)dd.A1[b * MAXN + e];
-                put_block(static_cast<PT*>(dd.Pnext), pn, (long)a * dd.dp + J * NB + qr * 16, (long)b * dd.dp + K * NB + qc * 16);
+                // The mirror image of block (a, b) lands in COLUMNS of derivative a of an upper tile.  P-' has two readers:
+                // the pairs of the next step (lower tiles only) and the gather of the next G = [H P- H^T + R; P- H^T],
+                // whose H touches the columns of derivatives 0 and 1 (h_row_load: (1, i) and the stencil (0, col)).  Nobody
+                // reads the upper tiles' columns of derivative >= 2: a sixth of this epilogue's 18.9 MB (n = 3) stays home.
+                put_block(static_cast<PT*>(dd.Pnext), pn, (long)a * dd.dp + J * NB + qr * 16, (long)b * dd.dp + K * NB + qc * 16, a < 2);
             }
     }
     SWEEP_STAMP(2);
