@@ -2807,6 +2807,12 @@ __global__ __launch_bounds__(256) void k_sweep_rl(const double* __restrict__ G, 
                     for (int s = 1; s < 8; ++s)
                         a = __builtin_amdgcn_mfma_f64_16x16x4f64(ax.v[s], b[k & 1].v[s], a, 0, 0, 0);
                     n[u - 1] = a;
+                } else {
+                    // (the exit edge of the unrolled loop: the wait states behind the last tile's chain sit HERE -- behind
+                    //  the loop they came behind the accumulator moves of the join, whose first read followed the chain's
+                    //  last MFMA by six wait states: tools/mfma_hazard_scan.py)
+                    mfma_result_guard();
+                    break;
                 }
             }
             mfma_result_guard();

@@ -68,12 +68,3 @@ for j in range(CB):
         continue
     print(f"j={j:2d} {us(a[0]):8.2f} " + (f"{us(a[1]):8.2f}" if a[1] > 0 else "       -") + f" {us(a[2]):8.2f} | {int(a[3])} {int(a[4])}")
 
-if LOOP and st[448, 0] > 0:
-    a = us(st[448])
-    print("tail workgroup (us): start %.2f | vector ops seen %.2f | m-, z out %.2f | all pairs seen %.2f | read-out out %.2f | counter moved %.2f" % tuple(a[:6]))
-    fr = st[449:512]
-    ok = fr[:, 0] > 0
-    f = us(fr[ok])
-    print(f"front workgroups (sample of {ok.sum()}): start min/median/max {f[:,0].min():.1f}/{np.median(f[:,0]):.1f}/{f[:,0].max():.1f}  tiles seen {f[:,1].min():.1f}/{np.median(f[:,1]):.1f}/{f[:,1].max():.1f}"
-          f"  done {f[:,5].min():.1f}/{np.median(f[:,5]):.1f}/{f[:,5].max():.1f}  gather {np.median(f[:,5]-f[:,1]):.2f} us")
-    print("  done, in sample order:", " ".join(f"{x:.0f}" for x in f[:, 5]))

@@ -31,3 +31,30 @@ s._device_filter.ctx.synchronize()
 t0 = lap("initialize_on_device (two update_sqrt + state upload)", t0)
 t["total"] = round(sum(t.values()), 3)
 print(json.dumps({"mesh": f"{n}x{n}", "seconds": t}))
+
+# finer: where the two large stages spend their time (second pass, same process: allocations are warm)
+if len(sys.argv) > 2 and sys.argv[2] == "--fine":
+    import functools
+    from pnmol.base import sqrt as dsqrt
+    acc = {}
+    def timed(name, fn):
+        @functools.wraps(fn)
+        def w(*a, **k):
+            t1 = time.perf_counter()
+            r = fn(*a, **k)
+            acc[name] = acc.get(name, 0.0) + time.perf_counter() - t1
+            return r
+        return w
+    dsqrt.update_sqrt = timed("update_sqrt (device QR incl. copies)", dsqrt.update_sqrt)
+    _hip.Context.cholesky = timed("Context.cholesky (device, incl. copies)", _hip.Context.cholesky)
+    _hip.State.set_sqrtm = timed("State.set_sqrtm (upload + C C^T)", _hip.State.set_sqrtm)
+    s.spatial_kernel.__class__.__call__ = timed("spatial_kernel(X, X^T) (host)", s.spatial_kernel.__class__.__call__)
+    t1 = time.perf_counter()
+    s.iwp, s.E0, s.E1, gamma = s.initialize_iwp(pde)
+    a = time.perf_counter() - t1
+    t1 = time.perf_counter()
+    mean, dev = s._initialize_on_device(pde, gamma)
+    s._device_filter.ctx.synchronize()
+    b = time.perf_counter() - t1
+    print(json.dumps({"fine": {k: round(v, 3) for k, v in acc.items()}, "initialize_iwp": round(a, 3),
+                      "initialize_on_device": round(b, 3)}))
