@@ -3247,6 +3247,121 @@ static double nordsieck_scale(int nu, int a, double dt) {  // base/iwp.py:55-62
 
 // struct pnmol_ctx: pnmol_internal.hpp
 
+// ------------------------------------------------------------------------------------------
+// Large problems (the 64x64 mesh of BASELINE config 5: D = 8192, m = 4348): P = P- - W W^T as ONE plain SYRK over the D x D
+// matrix -- the derivative-block structure plays no role in it -- on 128x128 tiles.  The pairs of 32-point tiles that ride
+// along in k_sweep read both operands per 32x32 tile (36 GB per step at that size, on top of the 33 GB of the sweep's own
+// re-reads, all L2 misses: the fused launch ran at the fabric's rate, 18.2 ms), and the stand-alone k_downdate
+// (16-point tiles) needs 11.6 ms.  Here a workgroup (4 waves, each a 64x64 quadrant = 4x4 MFMA tiles, 128 accumulator
+// registers) streams 16-column slabs of its two 128-row panels of W through LDS, K-major (conflict-free fragment reads:
+// the 16 lanes of a fragment row read 16 consecutive doubles), double-buffered, ONE barrier per slab of 64 MFMAs per wave,
+// two workgroups per CU.  Lower tiles only; the mirror image leaves through a wave-private LDS transpose as 128-byte rows.
+constexpr int BDT = 128;  // tile
+constexpr int BDK = 16;   // columns of W per slab
+__global__ __launch_bounds__(256, 2) void k_downdate_big(const double* Ppred, const double* __restrict__ W, double* Pout,
+                                                         double* __restrict__ var, long Dp, int mp, int nt) {
+    __shared__ __attribute__((aligned(16))) double sA[2][BDK][BDT];
+    __shared__ __attribute__((aligned(16))) double sB[2][BDK][BDT];
+    const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 1, wc = w & 1, fr = l & 15, fk = l >> 4;
+    // tile (I, J), J <= I.  Consecutive tiles of the row-major order go to the SAME XCD (blockIdx.x round-robins over the
+    // eight XCDs): the workgroups that share an L2 share the panel I and walk neighbouring panels J.
+    // (the launch has 8 * ceil(nt / 8) workgroups)
+    const int per = (int)gridDim.x / 8;
+    const int t = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);
+    if (t >= nt) return;
+    int I = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((I + 1) * (I + 2) / 2 <= t) ++I;
+    while (I * (I + 1) / 2 > t) --I;
+    const int J = t - I * (I + 1) / 2;
+    const long row0 = (long)I * BDT + wr * 64, col0 = (long)J * BDT + wc * 64;
+    d4 acc[4][4];
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[ti][tj][r] = Ppred[(row0 + 16 * ti + fk + 4 * r) * Dp + col0 + 16 * tj + fr];
+    // loader: thread -> (row tid / 2 of the panel, columns 8 (tid & 1) .. +7 of the slab)
+    const int lrow = tid >> 1, lk = (tid & 1) * 8;
+    const double* ga = W + ((long)I * BDT + lrow) * mp + lk;
+    const double* gb = W + ((long)J * BDT + lrow) * mp + lk;
+    double2 ra[4], rb[4];
+    auto fetch = [&](int slab) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ra[q] = *reinterpret_cast<const double2*>(ga + (long)slab * BDK + 2 * q);
+            rb[q] = *reinterpret_cast<const double2*>(gb + (long)slab * BDK + 2 * q);
+        }
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sA[buf][lk + 2 * q][lrow] = ra[q].x;
+            sA[buf][lk + 2 * q + 1][lrow] = ra[q].y;
+            sB[buf][lk + 2 * q][lrow] = rb[q].x;
+            sB[buf][lk + 2 * q + 1][lrow] = rb[q].y;
+        }
+    };
+    const int nslab = mp / BDK;
+    fetch(0);
+    park(0);
+    __syncthreads();
+    for (int sl = 0; sl < nslab; ++sl) {
+        const int buf = sl & 1;
+        if (sl + 1 < nslab) fetch(sl + 1);  // (in flight under this slab's MFMAs)
+#pragma unroll
+        for (int ks = 0; ks < BDK / 4; ++ks) {
+            double a[4], b[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                a[q] = -sA[buf][4 * ks + fk][wr * 64 + 16 * q + fr];
+                b[q] = sB[buf][4 * ks + fk][wc * 64 + 16 * q + fr];
+            }
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj)
+                    acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+        }
+        // (buffer buf ^ 1 was read in the previous iteration: everybody is past that iteration's barrier)
+        if (sl + 1 < nslab) park(buf ^ 1);
+        __syncthreads();
+    }
+    // the tile, diag(P)
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long row = row0 + 16 * ti + fk + 4 * r, col = col0 + 16 * tj + fr;
+                Pout[row * Dp + col] = acc[ti][tj][r];
+                if (row == col) var[row] = acc[ti][tj][r];
+            }
+    if (I == J) return;  // (a diagonal tile holds both of its triangles)
+    // mirror image: strips of 16 rows x 64 columns, transposed through this wave's 16 KB of the slab buffers
+    double* stg = (w < 2 ? &sA[0][0][0] : &sB[0][0][0]) + (w & 1) * (BDK * BDT);  // 2048 doubles (16 KB) of LDS per wave
+#pragma unroll  // (a run-time index into acc would put all 128 accumulator registers into scratch memory)
+    for (int ti = 0; ti < 4; ++ti) {
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stg[(16 * tj + fr) * 17 + fk + 4 * r] = acc[ti][tj][r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int c = fk + 4 * q;  // column of the tile = row of the mirror image
+            Pout[(col0 + c) * Dp + row0 + 16 * ti + fr] = stg[c * 17 + fr];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+// the vector ops of the step as a launch of their own (k_downdate carries them in extra blockIdx.y rows)
+__global__ __launch_bounds__(256) void k_vecops(VecArgs va, const double* __restrict__ W, int mp, long Dp, int per_row) {
+    vecops_rows(va, W, mp, Dp, ((long)blockIdx.y * per_row + blockIdx.x) * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+}
+
 struct pnmol_filter {
     pnmol_ctx* ctx = nullptr;
     int d = 0, n = 0, nu = 0, nB = 0, m = 0, dp = 0, mp = 0, CB = 0, RBS = 0, RBW = 0, RT = 0, ellw = 0;
@@ -3256,6 +3371,7 @@ struct pnmol_filter {
     int* flags = nullptr;  // k_sweep dependency flags: row[RT], diag[CB], abort, claim[CB*CB] (helpers); k_sweep_rl: rl_flags()
     int nflags = 0;        // words allocated (all of them are zeroed before every sweep)
     double* hs_scratch = nullptr;  // helpers' partial sums, one tile per (row, target step)
+    int dd_big = 0;        // large problems: sweep alone + k_downdate_big (PNMOL_HIP_DD_BIG=0/1 overrides; see there)
     int sweep_mode = 2;    // PNMOL_HIP_SWEEP: 2 = k_sweep with the covariance down-date riding along in the same launch,
                            // 1 = k_sweep, then k_downdate; 0 = k_diag0 + one k_panel launch per panel, then k_downdate
     int ds = 0;  // spatial components of the state (= d, or 2d for the latent-force model [u; eps])
@@ -3450,7 +3566,13 @@ int launch_step(pnmol_filter* f, const double* Pin, const double* min, double fr
         // K4: P = P- - W W^T (tiles) and, in extra blockIdx.y rows of the same launch, the vector ops
         const int tiles = dp / 16;
         const int vrows = (int)(((Dp + mp + 3) / 4 + tiles - 1) / tiles);
-        k_downdate<N><<<dim3(tiles, tiles + vrows), 256, 0, st>>>(f->Ppred, W, Pout, varout, dp, mp, 0, mp / 8, va);
+        if (f->dd_big) {
+            const int T = (int)(Dp / BDT), nt = T * (T + 1) / 2;
+            k_downdate_big<<<8 * ((nt + 7) / 8), 256, 0, st>>>(static_cast<const double*>(f->Ppred), W, Pout, varout, Dp, mp, nt);
+            k_vecops<<<dim3(tiles, vrows), 256, 0, st>>>(va, W, mp, Dp, tiles);
+        } else {
+            k_downdate<N><<<dim3(tiles, tiles + vrows), 256, 0, st>>>(f->Ppred, W, Pout, varout, dp, mp, 0, mp / 8, va);
+        }
     }
     // K5: read-out + deterministic reduction of the per-row partial sums
     IwpConsts cn = f->iwp;  // the next step of the loop has the same dt: no frame change
@@ -3932,6 +4054,17 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
     if (const char* gc = std::getenv("PNMOL_HIP_GRAPH_CHUNK")) f->graph_chunk = std::atoi(gc) / 2 * 2;
     if (const char* e = std::getenv("PNMOL_HIP_SWEEP")) f->sweep_mode = std::atoi(e);
     if (f->sweep_mode == 2 && n > 3) f->sweep_mode = 1;  // the fused down-date role is built for n <= 3
+    {
+        // Large fp64 problems (from D = 4096 with more column blocks than the register-resident sweep holds): the sweep
+        // alone, then the SYRK of k_downdate_big -- measured on the 64x64 mesh against the fused launch (see k_downdate_big)
+        const char* e = std::getenv("PNMOL_HIP_DD_BIG");
+        const bool fits = !f->p32 && f->Dp % BDT == 0 && f->mp % BDK == 0 && f->sweep_mode >= 1;
+        const bool want = e ? std::atoi(e) != 0 : (f->Dp >= 8192 && f->CB > 17);
+        if (fits && want) {
+            f->dd_big = 1;
+            f->sweep_mode = 1;
+        }
+    }
     {
         // XCD-local layout (k_sweep_rl<.., XL>): only a filter that launches k_sweep_rl is counted, per device; unless
         // PNMOL_HIP_SWEEP_XL forces it, the first such filter alive on its device gets the layout (pnmol_filter_sweep_layout
