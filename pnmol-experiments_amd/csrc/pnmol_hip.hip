@@ -848,6 +848,31 @@ __global__ __launch_bounds__(256) void k_front(const void* __restrict__ Ppred, d
     else front_block(static_cast<const double*>(Ppred), G, rdiag, Rdense, mm, Dp, blockIdx.x, blockIdx.y);
 }
 
+// S = H (P- H^T) + R from the rows of P- H^T that k_front has just written into G (a launch of its own behind it).  For
+// wide stencils (2-d meshes: 5 neighbours + the derivative entry) s_entry's (w + 1)^2 = 36 dependent gathers per entry of S
+// become w + 1 = 6 coalesced loads: G[mp + y][i] IS h_row_dot(i, row y of P-), the inner sum s_entry forms, so the entries
+// are the same numbers in the same association order.  Block-lower part only, identity on the padding (as front_block).
+__global__ __launch_bounds__(256) void k_front_s(double* __restrict__ G, const double* __restrict__ rdiag,
+                                                 const double* __restrict__ Rdense, MeasModel mm) {
+    const int i = blockIdx.x * 256 + threadIdx.x, ip = blockIdx.y, mp = mm.mp;
+    if (i >= mp || i >= (ip / NB + 1) * NB) return;
+    double v;
+    if (ip >= mm.m || i >= mm.m) {
+        v = (ip == i) ? 1.0 : 0.0;
+    } else {
+        const double* PHt = G + (long)mp * mp;
+        v = 0.0;
+        if (ip < mm.d) v = mm.c1 * PHt[(long)(mm.dp + ip) * mp + i];
+        for (int e = 0; e < mm.w; ++e) {
+            const int cidx = mm.ell_col[e * mp + ip];
+            if (cidx >= 0) v += mm.c0 * mm.ell_val[e * mp + ip] * PHt[(long)cidx * mp + i];
+        }
+        if (ip == i) v += rdiag[i];
+        if (Rdense) v += Rdense[(long)ip * mp + i];
+    }
+    G[(long)ip * mp + i] = v;
+}
+
 // first diagonal block: diag(S) -> sdiag, its max -> sdiag[mp]; F[0,0] = chol(G[0,0]), Linv[0] = its inverse
 __global__ __launch_bounds__(128) void k_diag0(const double* __restrict__ G, double* __restrict__ F,
                                                double* __restrict__ Linv, int ld, int* info_base,
@@ -3528,9 +3553,16 @@ int launch_step(pnmol_filter* f, const double* Pin, const double* min, double fr
         k_predict<N><<<dim3(dp / 32, dp / 8 + 1), dim3(32, 8), sizeof(double) * Dp, st>>>(
         Pin, f->Ppred, f->Kg, c, dp, min, f->mpred, f->shift, f->G, f->zbuf, mm, f->ctr, f->flags, f->nflags, f->p32);
     // K2: G = [S; P-H^T; z; I]  (STEADY: done by the previous step's k_readout launch)
-    if (kind != STEP_STEADY)
-        k_front<<<dim3((mp + 255) / 256, (unsigned)(Dp + mp + (f->sweep_mode == 0 ? mp : 0))), 256, 0, st>>>(
-            f->Ppred, f->G, f->rdiag, f->Rdense, mm, Dp, f->p32);  // (the per-panel path updates G in place: identity block too)
+    if (kind != STEP_STEADY) {
+        if (f->ellw > HW && f->sweep_mode != 0) {
+            // wide stencils (and sweep kernels that leave G alone): the rows of P- H^T first, S from them (k_front_s)
+            k_front<<<dim3((mp + 255) / 256, (unsigned)Dp), 256, 0, st>>>(f->Ppred, f->G, f->rdiag, f->Rdense, mm, Dp, f->p32);
+            k_front_s<<<dim3((mp + 255) / 256, (unsigned)mp), 256, 0, st>>>(f->G, f->rdiag, f->Rdense, mm);
+        } else {
+            k_front<<<dim3((mp + 255) / 256, (unsigned)(Dp + mp + (f->sweep_mode == 0 ? mp : 0))), 256, 0, st>>>(
+                f->Ppred, f->G, f->rdiag, f->Rdense, mm, Dp, f->p32);  // (the per-panel path updates G in place: identity block too)
+        }
+    }
     const long rowI0 = (long)mp + Dp + NB;
     const double* W = f->F + (long)mp * mp;
     const bool have_sq = (f->Sqinv != nullptr && f->sq_dt == dt);
