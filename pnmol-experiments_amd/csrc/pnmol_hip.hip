@@ -3283,10 +3283,14 @@ static double nordsieck_scale(int nu, int a, double dt) {  // base/iwp.py:55-62
 // two workgroups per CU.  Lower tiles only; the mirror image leaves through a wave-private LDS transpose as 128-byte rows.
 constexpr int BDT = 128;  // tile
 constexpr int BDK = 16;   // columns of W per slab
-__global__ __launch_bounds__(256, 2) void k_downdate_big(const double* Ppred, const double* __restrict__ W, double* Pout,
+// PT = float: the covariance is fp32 (pnmol_filter_desc.dtype = 1): W is rounded to fp32 on its way into LDS, the products run on
+// v_mfma_f32_16x16x4_f32 with fp32 accumulators (the arithmetic of the fused pairs' fp32 form), half the LDS, half the registers.
+template <typename PT>
+__global__ __launch_bounds__(256, 2) void k_downdate_big(const PT* Ppred, const double* __restrict__ W, PT* Pout,
                                                          double* __restrict__ var, long Dp, int mp, int nt) {
-    __shared__ __attribute__((aligned(16))) double sA[2][BDK][BDT];
-    __shared__ __attribute__((aligned(16))) double sB[2][BDK][BDT];
+    typedef typename AccOf<PT>::type acc_t;
+    __shared__ __attribute__((aligned(16))) PT sA[2][BDK][BDT];
+    __shared__ __attribute__((aligned(16))) PT sB[2][BDK][BDT];
     const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = w >> 1, wc = w & 1, fr = l & 15, fk = l >> 4;
     // tile (I, J), J <= I.  Consecutive tiles of the row-major order go to the SAME XCD (blockIdx.x round-robins over the
@@ -3300,13 +3304,14 @@ __global__ __launch_bounds__(256, 2) void k_downdate_big(const double* Ppred, co
     while (I * (I + 1) / 2 > t) --I;
     const int J = t - I * (I + 1) / 2;
     const long row0 = (long)I * BDT + wr * 64, col0 = (long)J * BDT + wc * 64;
-    d4 acc[4][4];
+    acc_t acc[4][4];
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[ti][tj][r] = Ppred[(row0 + 16 * ti + fk + 4 * r) * Dp + col0 + 16 * tj + fr];
+            for (int r = 0; r < 4; ++r)
+                acc[ti][tj][r] = Ppred[(row0 + 16 * ti + AccOf<PT>::row(fk, r)) * Dp + col0 + 16 * tj + fr];
     // loader: thread -> (row tid / 2 of the panel, columns 8 (tid & 1) .. +7 of the slab)
     const int lrow = tid >> 1, lk = (tid & 1) * 8;
     const double* ga = W + ((long)I * BDT + lrow) * mp + lk;
@@ -3322,10 +3327,10 @@ __global__ __launch_bounds__(256, 2) void k_downdate_big(const double* Ppred, co
     auto park = [&](int buf) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            sA[buf][lk + 2 * q][lrow] = ra[q].x;
-            sA[buf][lk + 2 * q + 1][lrow] = ra[q].y;
-            sB[buf][lk + 2 * q][lrow] = rb[q].x;
-            sB[buf][lk + 2 * q + 1][lrow] = rb[q].y;
+            sA[buf][lk + 2 * q][lrow] = (PT)ra[q].x;
+            sA[buf][lk + 2 * q + 1][lrow] = (PT)ra[q].y;
+            sB[buf][lk + 2 * q][lrow] = (PT)rb[q].x;
+            sB[buf][lk + 2 * q + 1][lrow] = (PT)rb[q].y;
         }
     };
     const int nslab = mp / BDK;
@@ -3337,7 +3342,7 @@ __global__ __launch_bounds__(256, 2) void k_downdate_big(const double* Ppred, co
         if (sl + 1 < nslab) fetch(sl + 1);  // (in flight under this slab's MFMAs)
 #pragma unroll
         for (int ks = 0; ks < BDK / 4; ++ks) {
-            double a[4], b[4];
+            PT a[4], b[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 a[q] = -sA[buf][4 * ks + fk][wr * 64 + 16 * q + fr];
@@ -3346,8 +3351,10 @@ __global__ __launch_bounds__(256, 2) void k_downdate_big(const double* Ppred, co
 #pragma unroll
             for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
-                for (int tj = 0; tj < 4; ++tj)
-                    acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+                for (int tj = 0; tj < 4; ++tj) {
+                    if constexpr (sizeof(PT) == 8) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+                    else acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+                }
         }
         // (buffer buf ^ 1 was read in the previous iteration: everybody is past that iteration's barrier)
         if (sl + 1 < nslab) park(buf ^ 1);
@@ -3360,19 +3367,19 @@ __global__ __launch_bounds__(256, 2) void k_downdate_big(const double* Ppred, co
         for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const long row = row0 + 16 * ti + fk + 4 * r, col = col0 + 16 * tj + fr;
+                const long row = row0 + 16 * ti + AccOf<PT>::row(fk, r), col = col0 + 16 * tj + fr;
                 Pout[row * Dp + col] = acc[ti][tj][r];
                 if (row == col) var[row] = acc[ti][tj][r];
             }
     if (I == J) return;  // (a diagonal tile holds both of its triangles)
-    // mirror image: strips of 16 rows x 64 columns, transposed through this wave's 16 KB of the slab buffers
-    double* stg = (w < 2 ? &sA[0][0][0] : &sB[0][0][0]) + (w & 1) * (BDK * BDT);  // 2048 doubles (16 KB) of LDS per wave
-#pragma unroll  // (a run-time index into acc would put all 128 accumulator registers into scratch memory)
+    // mirror image: strips of 16 rows x 64 columns, transposed through this wave's quarter of the slab buffers
+    PT* stg = (w < 2 ? &sA[0][0][0] : &sB[0][0][0]) + (w & 1) * (BDK * BDT);  // 2048 elements of LDS per wave
+#pragma unroll  // (a run-time index into acc would put all accumulator registers into scratch memory)
     for (int ti = 0; ti < 4; ++ti) {
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) stg[(16 * tj + fr) * 17 + fk + 4 * r] = acc[ti][tj][r];
+            for (int r = 0; r < 4; ++r) stg[(16 * tj + fr) * 17 + AccOf<PT>::row(fk, r)] = acc[ti][tj][r];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -3585,7 +3592,7 @@ int launch_step(pnmol_filter* f, const double* Pin, const double* min, double fr
         if (f->sweep_mode == 1) {
             // K3': the sweep alone as one dataflow launch
             launch_sweep<N, false>(f->RT, st, f->G, f->F, f->Linv, mp, f->CB, f->RT, f->flags, f->info, f->ctr, dd,
-                                   f->flags + f->RT + f->CB + 1, f->hs_scratch, 0, f->xcd_home);
+                                   f->flags + f->RT + f->CB + 1, f->hs_scratch, f->p32 ? 2 : 0, f->xcd_home);
         } else {
             k_diag0<<<1, 128, 0, st>>>(f->G, f->F, f->Linv, mp, f->info, f->sdiag, f->ctr);
             // K3: right-looking sweep, one launch per 32-column panel
@@ -3600,7 +3607,12 @@ int launch_step(pnmol_filter* f, const double* Pin, const double* min, double fr
         const int vrows = (int)(((Dp + mp + 3) / 4 + tiles - 1) / tiles);
         if (f->dd_big) {
             const int T = (int)(Dp / BDT), nt = T * (T + 1) / 2;
-            k_downdate_big<<<8 * ((nt + 7) / 8), 256, 0, st>>>(static_cast<const double*>(f->Ppred), W, Pout, varout, Dp, mp, nt);
+            if (f->p32)
+                k_downdate_big<float><<<8 * ((nt + 7) / 8), 256, 0, st>>>(reinterpret_cast<const float*>(f->Ppred), W,
+                                                                          reinterpret_cast<float*>(Pout), varout, Dp, mp, nt);
+            else
+                k_downdate_big<double><<<8 * ((nt + 7) / 8), 256, 0, st>>>(static_cast<const double*>(f->Ppred), W, Pout, varout,
+                                                                           Dp, mp, nt);
             k_vecops<<<dim3(tiles, vrows), 256, 0, st>>>(va, W, mp, Dp, tiles);
         } else {
             k_downdate<N><<<dim3(tiles, tiles + vrows), 256, 0, st>>>(f->Ppred, W, Pout, varout, dp, mp, 0, mp / 8, va);
@@ -4090,7 +4102,7 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
         // Large fp64 problems (from D = 4096 with more column blocks than the register-resident sweep holds): the sweep
         // alone, then the SYRK of k_downdate_big -- measured on the 64x64 mesh against the fused launch (see k_downdate_big)
         const char* e = std::getenv("PNMOL_HIP_DD_BIG");
-        const bool fits = !f->p32 && f->Dp % BDT == 0 && f->mp % BDK == 0 && f->sweep_mode >= 1;
+        const bool fits = f->Dp % BDT == 0 && f->mp % BDK == 0 && f->sweep_mode >= 1 && (!f->p32 || f->sweep_mode == 2);
         const bool want = e ? std::atoi(e) != 0 : (f->Dp >= 8192 && f->CB > 17);
         if (fits && want) {
             f->dd_big = 1;
@@ -4124,7 +4136,7 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
     FCHK(hipMemset(f->last_ctr, 0, sizeof(int)));
     FCHK(hipMalloc(&f->tickets, sizeof(int)));
     FCHK(hipMemset(f->tickets, 0, sizeof(int)));
-    if (f->p32 && f->sweep_mode != 2) {
+    if (f->p32 && f->sweep_mode != 2 && !f->dd_big) {
         ctx->err = "pnmol_filter_create: dtype = fp32 covariance needs the fused sweep (num_derivatives <= 2, PNMOL_HIP_SWEEP unset)";
         return fail(-1);
     }

@@ -12,7 +12,7 @@ from helpers import assert_mean_std_parity
 pytestmark = pytest.mark.gpu
 
 
-def _solve(nums, K, dt, force):
+def _solve(nums, K, dt, force, dtype="f64"):
     import pnmol
 
     old = os.environ.get("PNMOL_HIP_DD_BIG")
@@ -22,6 +22,7 @@ def _solve(nums, K, dt, force):
                                                                kernel=pnmol.kernels.SquareExponential())
         solver = pnmol.white.LinearWhiteNoiseEK1(num_derivatives=1, steprule=pnmol.odetools.step.Constant(dt),
                                                  spatial_kernel=pnmol.kernels.Matern52() + pnmol.kernels.WhiteNoise())
+        solver.dtype = dtype
         t, means, stds, sig, final = solver.solve_marginals(pde)
         cov = np.array(final.y.cov)
         return means, stds, sig, cov
@@ -57,3 +58,17 @@ def test_big_downdate_against_the_oracle(hip_ctx):
     osol = osolver.solve(opde)
     omeans, ostds = oracle.read_mean_and_std(osol, osolver.E0)
     assert_mean_std_parity(means, stds, omeans, ostds)
+
+
+def test_big_downdate_fp32_covariance(hip_ctx):
+    """dtype = "f32" (BASELINE config 5's precision): the fp32 SYRK against the fp32 form of the fused pairs -- the same
+    arithmetic types (W rounded to fp32, v_mfma_f32_16x16x4_f32, fp32 accumulators) in another association order: agreement
+    at the resolution of an fp32 covariance (6e-8 |P|), i.e. the floor DESIGN.md section 11 describes for the stds."""
+    dt, K = 2.0 ** -9, 4
+    m0, s0, g0, c0 = _solve((16, 16), K, dt, "0", "f32")
+    m1, s1, g1, c1 = _solve((16, 16), K, dt, "1", "f32")
+    np.testing.assert_allclose(m1, m0, rtol=0, atol=1e-7 * np.abs(m0).max())
+    np.testing.assert_allclose(c1, c0, rtol=0, atol=5e-6 * np.abs(c0).max())
+    big = s0 > 1e-2 * s0.max()
+    np.testing.assert_allclose(s1[big], s0[big], rtol=1e-3)
+    np.testing.assert_allclose(g1, g0, rtol=1e-4)
