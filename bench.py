@@ -14,7 +14,7 @@ MFMA peak with the ALGORITHMIC flop count F_alg of SURVEY.md section 8d (never t
 At N=1 the line also carries (each driver-timed inside this run):
   batch8_on_1gpu   the 8-problem kappa sweep on this ONE GPU, problems one after the other and all in flight
                    -- the 1-GPU baseline north_star's ">= 6x at 8 GPUs on an 8-problem batch" refers to
-  secondary        ms/step at N=256, N=1024 and on the 64x64 2-d mesh (BASELINE configs 1, 2, 4; fp64)
+  secondary        ms/step at N=256, N=1024 (fp64) and on the 64x64 2-d mesh (fp64 and fp32 covariance): BASELINE configs 2, 3, 5
   library_baseline_ms_per_step   the same step written with torch-ROCm library calls (tools/torch_library_step.py)
 """
 
@@ -190,26 +190,33 @@ def secondary_points(device):
             del ctx, flt, dev
         except Exception as e:   # a secondary point must never take the headline line down
             out.append({"workload": f"1-D heat N={mesh_n} nu={NU}", "error": repr(e)[:200]})
-    try:
-        import pnmol
-        dt2, K = 2.0 ** -9, 4
-        pde = pnmol.pde.examples.heat_2d_dirichlet_discretized(nums=(64, 64), tmax=(K + 2) * dt2, diffusion_rate=0.05,
-                                                               kernel=pnmol.kernels.SquareExponential())
-        solver = pnmol.white.LinearWhiteNoiseEK1(num_derivatives=1, steprule=pnmol.odetools.step.Constant(dt2),
-                                                 spatial_kernel=pnmol.kernels.Matern52() + pnmol.kernels.WhiteNoise())
-        state = solver.initialize(pde)
-        flt, dev = solver._device_filter, state.y.device_state
-        solver._ensure_error_model(pde, dt2)
-        flt.steps(dev, 1, dt2)
-        flt.prepare_steps(dev, K, dt2)
-        flt.steps(dev, K, dt2)
-        ms = flt.last_steps_ms() / K
-        dd = flt.dims()
-        D, mm, nn = dd["n"] * dd["d"], dd["m"], dd["n"]
-        out.append({"workload": "2-D heat 64x64 mesh nu=1 (fp64)", "ms_per_step": ms,
-                    "frac_of_fp64_mfma_peak": f_alg(D, mm, nn) / (ms * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS})
-    except Exception as e:
-        out.append({"workload": "2-D heat 64x64 mesh nu=1 (fp64)", "error": repr(e)[:200]})
+    # BASELINE config 5's mesh in fp64 and in its stated precision (fp32 covariance)
+    for dtype in ("f64", "f32"):
+        name = f"2-D heat 64x64 mesh nu=1 ({'fp64' if dtype == 'f64' else 'fp32 covariance'})"
+        try:
+            import pnmol
+            dt2, K = 2.0 ** -9, 4
+            pde = pnmol.pde.examples.heat_2d_dirichlet_discretized(nums=(64, 64), tmax=(K + 2) * dt2, diffusion_rate=0.05,
+                                                                   kernel=pnmol.kernels.SquareExponential())
+            solver = pnmol.white.LinearWhiteNoiseEK1(num_derivatives=1, steprule=pnmol.odetools.step.Constant(dt2),
+                                                     spatial_kernel=pnmol.kernels.Matern52() + pnmol.kernels.WhiteNoise())
+            solver.dtype = dtype
+            state = solver.initialize(pde)
+            flt, dev = solver._device_filter, state.y.device_state
+            solver._ensure_error_model(pde, dt2)
+            flt.steps(dev, 1, dt2)
+            flt.prepare_steps(dev, K, dt2)
+            flt.steps(dev, K, dt2)
+            ms = flt.last_steps_ms() / K
+            dd = flt.dims()
+            D, mm, nn = dd["n"] * dd["d"], dd["m"], dd["n"]
+            row = {"workload": name, "ms_per_step": ms}
+            if dtype == "f64":
+                row["frac_of_fp64_mfma_peak"] = f_alg(D, mm, nn) / (ms * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS
+            out.append(row)
+            del solver, state, flt, dev
+        except Exception as e:
+            out.append({"workload": name, "error": repr(e)[:200]})
     try:
         # semilinear EK1 (white.py:189-208) on the reference's spruce-budworm recipe: one attempt_step per call -- predicted
         # mean to the host, f / df there (Python callables, as in the reference), new stencil rows to the device, step
