@@ -1750,19 +1750,25 @@ __device__ __forceinline__ void sweep_downdate_role(SweepLds& L, const DowndateA
 template <int N, bool FUSED, bool CHAINHELP = FUSED>
 __global__ __launch_bounds__(256) void k_sweep(const double* __restrict__ G, double* F, double* Linv, int ld, int CB,
                                                int RT, int* flags, int* info_base, const int* __restrict__ ctr,
-                                               DowndateArgs dd, int* claim, double* hs_scratch, int lenient) {
+                                               DowndateArgs dd, int* claim, double* hs_scratch, int lenient, int wskip) {
     __shared__ __attribute__((aligned(16))) SweepLds L;
     const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);  // w: wave-uniform (SGPR)
     const int wr = w >> 1, wc = w & 1, fr = l & 15, fk = l >> 4;
     // Block -> row block.  The r^T block (row block zb of the tall matrix) is dealt right behind the rows of S, before the
     // rows of W and of Ls^-T, which wait for it at their end (vector ops): dependencies keep pointing to lower blocks.
+    // wskip (large problems, !FUSED): the launch has no workgroups for the rows of W -- W = (P- H^T) Ls^-T is one GEMM behind
+    // this launch (k_w_gemm) -- : blocks [0, CB) rows of S, CB the r^T block, CB + 1 .. 2 CB the rows of Ls^-T.
     int I = blockIdx.x;
 #ifdef PNMOL_SWEEP_STAMP
     if (tid == 0) L.stamp_id = blockIdx.x;
 #endif
     {
         const int zb = RT - CB - 1;
-        if (I >= CB && I <= zb) I = (I == CB) ? zb : I - 1;
+        if (wskip) {
+            if (I >= CB) I = zb + (I - CB);
+        } else if (I >= CB && I <= zb) {
+            I = (I == CB) ? zb : I - 1;
+        }
     }
     const bool chain = I < CB;
     int* frow = flags;            // [RT]  chain rows: tiles of the row published; other rows: steps completed
@@ -3389,6 +3395,79 @@ __global__ __launch_bounds__(256, 2) void k_downdate_big(const PT* Ppred, const 
         __builtin_amdgcn_wave_barrier();
     }
 }
+// W = (P- H^T) T,  T = Ls^-T as the sweep leaves it in the identity rows of F (every row block of the tall matrix is
+// right-multiplied by the same operator, so the rows of W need not go through the sweep at all: on the 64x64 mesh they were
+// 256 of its 529 workgroups and 155 of its 210 GFLOP, at the left-looking kernel's 21 TF).  One GEMM on 128x128 tiles with
+// k_downdate_big's pipeline: A = 16-column slabs of 128 rows of P- H^T (K-major in LDS), B = 16 ROWS of T x 128 columns (K-major
+// as they lie in memory); T is upper triangular: column tile J needs k < 128 (J + 1) only, the tiles are dealt by falling J.
+__global__ __launch_bounds__(256, 2) void k_w_gemm(const double* __restrict__ A, const double* __restrict__ T, double* __restrict__ C,
+                                                   int ld, int nI, int nt) {
+    __shared__ __attribute__((aligned(16))) double sA[2][BDK][BDT];
+    __shared__ __attribute__((aligned(16))) double sB[2][BDK][BDT];
+    const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 1, wc = w & 1, fr = l & 15, fk = l >> 4;
+    // (tiles in dispatch order = by falling work, round-robin over the XCDs: with consecutive tiles on ONE XCD -- as in
+    //  k_downdate_big, where all tiles cost the same -- XCD 0 got the 272 longest tiles and the launch took 5.3 ms for 2.9 ms of work)
+    const int t = (int)blockIdx.x;
+    if (t >= nt) return;
+    const int nJ = nt / nI, J = nJ - 1 - t / nI, I = t % nI;
+    d4 acc[4][4];
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = (d4){0, 0, 0, 0};
+    const int lrow = tid >> 1, lk = (tid & 1) * 8;        // A: row of the panel, 8 columns of the slab
+    const int bk = tid >> 4, bj = (tid & 15) * 8;         // B: row of the slab, 8 columns of the tile
+    const double* ga = A + ((long)I * BDT + lrow) * ld + lk;
+    const double* gb = T + (long)bk * ld + (long)J * BDT + bj;
+    double2 ra[4], rb[4];
+    auto fetch = [&](int slab) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ra[q] = *reinterpret_cast<const double2*>(ga + (long)slab * BDK + 2 * q);
+            rb[q] = *reinterpret_cast<const double2*>(gb + (long)slab * BDK * ld + 2 * q);
+        }
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sA[buf][lk + 2 * q][lrow] = ra[q].x;
+            sA[buf][lk + 2 * q + 1][lrow] = ra[q].y;
+            *reinterpret_cast<double2*>(&sB[buf][bk][bj + 2 * q]) = rb[q];
+        }
+    };
+    const int nslab = (J + 1) * BDT / BDK;
+    fetch(0);
+    park(0);
+    __syncthreads();
+    for (int sl = 0; sl < nslab; ++sl) {
+        const int buf = sl & 1;
+        if (sl + 1 < nslab) fetch(sl + 1);
+#pragma unroll
+        for (int ks = 0; ks < BDK / 4; ++ks) {
+            double a[4], b[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                a[q] = sA[buf][4 * ks + fk][wr * 64 + 16 * q + fr];
+                b[q] = sB[buf][4 * ks + fk][wc * 64 + 16 * q + fr];
+            }
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj)
+                    acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+        }
+        if (sl + 1 < nslab) park(buf ^ 1);
+        __syncthreads();
+    }
+    const long row0 = (long)I * BDT + wr * 64, col0 = (long)J * BDT + wc * 64;
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) C[(row0 + 16 * ti + fk + 4 * r) * ld + col0 + 16 * tj + fr] = acc[ti][tj][r];
+}
 // the vector ops of the step as a launch of their own (k_downdate carries them in extra blockIdx.y rows)
 __global__ __launch_bounds__(256) void k_vecops(VecArgs va, const double* __restrict__ W, int mp, long Dp, int per_row) {
     vecops_rows(va, W, mp, Dp, ((long)blockIdx.y * per_row + blockIdx.x) * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
@@ -3403,6 +3482,7 @@ struct pnmol_filter {
     int* flags = nullptr;  // k_sweep dependency flags: row[RT], diag[CB], abort, claim[CB*CB] (helpers); k_sweep_rl: rl_flags()
     int nflags = 0;        // words allocated (all of them are zeroed before every sweep)
     double* hs_scratch = nullptr;  // helpers' partial sums, one tile per (row, target step)
+    int w_gemm = 0;        // ... and W = (P- H^T) Ls^-T as a GEMM behind a sweep without the rows of W (k_w_gemm)
     int dd_big = 0;        // large problems: sweep alone + k_downdate_big (PNMOL_HIP_DD_BIG=0/1 overrides; see there)
     int sweep_mode = 2;    // PNMOL_HIP_SWEEP: 2 = k_sweep with the covariance down-date riding along in the same launch,
                            // 1 = k_sweep, then k_downdate; 0 = k_diag0 + one k_panel launch per panel, then k_downdate
@@ -3508,7 +3588,8 @@ constexpr int MAX_DEVICES = 64;
 std::atomic<int> live_rl_filters[MAX_DEVICES];
 template <int N, bool FUSED>
 void launch_sweep(unsigned grid, hipStream_t st, const double* G, double* F, double* Linv, int ld, int CB, int RT, int* flags,
-                  int* info, const int* ctr, const DowndateArgs& dd, int* claim, double* hs, int lenient, int home) {
+                  int* info, const int* ctr, const DowndateArgs& dd, int* claim, double* hs, int lenient, int home,
+                  bool wskip = false) {
     // k_sweep_rl: block 0 is the chain workgroup; `hs` (>= 2 CB tiles) carries what the chain rows feed it; the CB flags
     // behind the abort word (`claim`) say so
     // XL (row blocks of S on the chain workgroup's XCD: blocks 8 s, the blocks between them empty)
@@ -3528,7 +3609,7 @@ void launch_sweep(unsigned grid, hipStream_t st, const double* G, double* F, dou
         else k_sweep_rl<N, FUSED, 17, false><<<rgrid + 1, 256, 0, st>>>(G, F, Linv, ld, CB, RT, flags, info, ctr, dd, hs, lenient, home);
     }
     else  // (a 33-tile row block no longer fits the register file: measured 1280 us against 666 at N = 1024)
-        k_sweep<N, FUSED><<<grid, 256, 0, st>>>(G, F, Linv, ld, CB, RT, flags, info, ctr, dd, claim, hs, lenient);
+        k_sweep<N, FUSED><<<grid, 256, 0, st>>>(G, F, Linv, ld, CB, RT, flags, info, ctr, dd, claim, hs, lenient, wskip ? 1 : 0);
 }
 
 inline bool short_last_panel() {  // PNMOL_HIP_SHORT_LAST=0: A/B switch
@@ -3591,6 +3672,13 @@ int launch_step(pnmol_filter* f, const double* Pin, const double* min, double fr
     } else {
         if (f->sweep_mode == 1) {
             // K3': the sweep alone as one dataflow launch
+            if (f->w_gemm) {
+                // rows of S, r^T, rows of Ls^-T through the sweep; W = (P- H^T) Ls^-T as a GEMM behind it
+                launch_sweep<N, false>(2 * f->CB + 1, st, f->G, f->F, f->Linv, mp, f->CB, f->RT, f->flags, f->info, f->ctr, dd,
+                                       f->flags + f->RT + f->CB + 1, f->hs_scratch, f->p32 ? 2 : 0, f->xcd_home, true);
+                const int nI = (int)(Dp / BDT), nt = nI * (mp / BDT);
+                k_w_gemm<<<8 * ((nt + 7) / 8), 256, 0, st>>>(f->G + (long)mp * mp, f->F + rowI0 * mp, f->F + (long)mp * mp, mp, nI, nt);
+            } else
             launch_sweep<N, false>(f->RT, st, f->G, f->F, f->Linv, mp, f->CB, f->RT, f->flags, f->info, f->ctr, dd,
                                    f->flags + f->RT + f->CB + 1, f->hs_scratch, f->p32 ? 2 : 0, f->xcd_home);
         } else {
@@ -4107,6 +4195,8 @@ int pnmol_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_fil
         if (fits && want) {
             f->dd_big = 1;
             f->sweep_mode = 1;
+            const char* g = std::getenv("PNMOL_HIP_W_GEMM");  // (0: the rows of W stay in the sweep; A/B switch)
+            f->w_gemm = (g ? std::atoi(g) != 0 : 1) && f->mp % BDT == 0 && f->CB > 17;  // (k_sweep, not k_sweep_rl)
         }
     }
     {

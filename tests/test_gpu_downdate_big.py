@@ -72,3 +72,24 @@ def test_big_downdate_fp32_covariance(hip_ctx):
     big = s0 > 1e-2 * s0.max()
     np.testing.assert_allclose(s1[big], s0[big], rtol=1e-3)
     np.testing.assert_allclose(g1, g0, rtol=1e-4)
+
+
+def test_w_as_a_gemm_behind_the_sweep(hip_ctx):
+    """32 x 20 mesh: D = 1280, m = 740 -> 768 = 6 x 128 padded columns, 24 column blocks: the large-problem path with the rows of
+    W taken out of the sweep (`k_w_gemm`: W = (P- H^T) Ls^-T with the Ls^-T the sweep leaves in the identity rows) against the
+    fused launch, and against the oracle.  Same operator applied to the same rows, as one product instead of a forward
+    substitution: agreement to rounding times the conditioning of S."""
+    dt, K = 2.0 ** -9, 3
+    m0, s0, g0, c0 = _solve((32, 20), K, dt, "0")
+    m1, s1, g1, c1 = _solve((32, 20), K, dt, "1")
+    np.testing.assert_allclose(m1, m0, rtol=0, atol=1e-11 * np.abs(m0).max())
+    np.testing.assert_allclose(c1, c0, rtol=0, atol=1e-11 * np.abs(c0).max())
+    np.testing.assert_allclose(s1, s0, rtol=1e-6, atol=1e-5 * s0.max())
+    np.testing.assert_allclose(g1, g0, rtol=1e-8)
+    opde = oracle.heat_2d_dirichlet_discretized(nums=(32, 20), tmax=K * dt, diffusion_rate=0.05,
+                                                kernel=oracle.SquareExponential())
+    osolver = oracle.WhiteNoiseEK1(num_derivatives=1, steprule=oracle.Constant(dt), canonical_factor_signs=True,
+                                   spatial_kernel=oracle.Matern52() + oracle.WhiteNoise())
+    osol = osolver.solve(opde)
+    omeans, ostds = oracle.read_mean_and_std(osol, osolver.E0)
+    assert_mean_std_parity(m1, s1, omeans, ostds)
