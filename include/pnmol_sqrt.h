@@ -47,7 +47,11 @@ int pnmol_sqrt_update_no_meascov(pnmol_ctx* ctx, const double* H, int m, int D, 
  * form to use when the factor itself is wanted, or when the covariance form's resolution (eps |P-|) is not enough.
  * Dense H.  The filter owns ONE state, advanced in place.  `pnmol_filter_desc` as in pnmol_hip.h: d_state 0 or d = white-noise model; d_state = 2d = latent-force model
  * (latent.py:155-233: L = [L, I], B = [B, 0], Gamma = blockdiag(chol K, E_sqrtm), zero noise factors -> the update is
- * `update_sqrt_no_meascov`); mean buffers are then (n, 2d) glued, the factor (2D, 2D) in the stacked order. */
+ * `update_sqrt_no_meascov`); mean buffers are then (n, 2d) glued, the factor (2D, 2D) in the stacked order.
+ * `desc->dtype`: 0 = fp64 (the reference's arithmetic, src/pnmol/__init__.py:9-11); 1 = the QRs in fp32 (pre-arrays rounded
+ * to fp32, Householder QR and compact-WY updates in fp32 on v_mfma_f32_16x16x4_f32; state, mean path, sigma^2 and all
+ * buffers of this interface stay double) -- the fp32 mode for num_derivatives >= 2, where the fp32 covariance form of
+ * pnmol_hip.h diverges; other values are refused with -1. */
 typedef struct pnmol_sqrt_filter pnmol_sqrt_filter;
 int pnmol_sqrt_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_sqrt_filter** out);
 int pnmol_sqrt_filter_destroy(pnmol_sqrt_filter* f);

@@ -1,4 +1,5 @@
-// pnmol_sqrt.hip -- square-root (QR) primitives of the PNMOL filter on MI355X (gfx950), fp64.
+// pnmol_sqrt.hip -- square-root (QR) primitives of the PNMOL filter on MI355X (gfx950): fp64, and an fp32 build of the QR
+// (work matrix, reflectors and trailing updates in fp32 on v_mfma_f32_16x16x4_f32) for the filter's dtype = 1 mode.
 //
 // What the reference does with `jnp.linalg.qr(mode="r")` (base/sqrt.py:8-95): the R factor of a tall stacked matrix.
 // Here: a communication-avoiding Householder QR (TSQR panels + compact-WY trailing updates on the f64 MFMA).
@@ -27,6 +28,7 @@
 namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int QB = 32;            // panel width = row-block height
 constexpr int FAN = 8;            // members per chunk
@@ -34,7 +36,23 @@ constexpr int CR = FAN * QB;      // stacked rows of a chunk (256)
 constexpr int FT = FAN * 64;      // threads of k_qr_factor: thread (k, g) = (t & 31, t >> 5), rows g, g + NG, ...
 constexpr int NG = FT / 32;       // row groups (16)
 constexpr int RPT = CR / NG;      // rows per thread (16)
-constexpr int VLD = 33;           // LDS row stride of V in k_qr_apply (bank-conflict-free column walks)
+
+// What differs between the two 16x16x4 MFMA forms: A[l & 15][k = l >> 4] and B[k = l >> 4][l & 15] are the same, the
+// accumulator is not -- register r of a lane with l >> 4 == fk is row fk + 4 r (f64) or row 4 fk + r (f32).  VLD: LDS row
+// stride of V in k_qr_apply (bank-conflict-free for the row walks of the first product and the column walks of the last).
+template <typename T> struct Mf;
+template <> struct Mf<double> {
+    typedef d4 acc_t;
+    static constexpr int VLD = 33;
+    static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int fk, int r) { return fk + 4 * r; }
+};
+template <> struct Mf<float> {
+    typedef f4 acc_t;
+    static constexpr int VLD = 36;
+    static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int fk, int r) { return 4 * fk + r; }
+};
 
 #define QCHECK(ctx, call)                                                                  \
     do {                                                                                   \
@@ -47,13 +65,14 @@ constexpr int VLD = 33;           // LDS row stride of V in k_qr_apply (bank-con
 
 constexpr int FLD = QB + 1;   // LDS row stride of the chunk in k_qr_factor
 
+template <typename T>
 struct FactorLds {
-    double A[CR * FLD];     // the chunk's panel columns (staging of the coalesced load), later V (unit lower trapezoidal)
-    double R[QB * QB];      // rows of R as they are finished
-    double G[QB * QB];      // V^T V
-    double tau[QB], scale[QB];
-    double col[2][CR];      // column J of the working matrix (ping-pong by step parity)
-    double rowb[2][QB];     // row J
+    T A[CR * FLD];     // the chunk's panel columns (staging of the coalesced load), later V (unit lower trapezoidal)
+    T R[QB * QB];      // rows of R as they are finished
+    T G[QB * QB];      // V^T V
+    T tau[QB], scale[QB];
+    T col[2][CR];      // column J of the working matrix (ping-pong by step parity)
+    T rowb[2][QB];     // row J
 };
 
 // The row blocks a panel's reflectors act on ("members"), in tree order: `ntop` consecutive blocks from the panel's own
@@ -76,6 +95,34 @@ __device__ __forceinline__ double row_ror_add(double x) {
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x120 + N, 0xf, 0xf, false);
     return x + __hiloint2double(hi, lo);
 }
+template <int N>
+__device__ __forceinline__ float row_ror_add(float x) {
+    return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x120 + N, 0xf, 0xf, false));
+}
+
+// 1 / sqrt(x) and 1 / x to the type's precision from the hardware estimates (two Newton steps for fp64, one for fp32)
+__device__ __forceinline__ double rsq_full(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * (1.5 - 0.5 * x * r * r);
+    return r * (1.5 - 0.5 * x * r * r);
+}
+__device__ __forceinline__ float rsq_full(float x) {
+    const float r = __builtin_amdgcn_rsqf(x);
+    return r * (1.5f - 0.5f * x * r * r);
+}
+__device__ __forceinline__ double rcp_full(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = r * (2.0 - x * r);
+    return r * (2.0 - x * r);
+}
+__device__ __forceinline__ float rcp_full(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    return r * (2.0f - x * r);
+}
+__device__ __forceinline__ double abs_t(double x) { return fabs(x); }
+__device__ __forceinline__ float abs_t(float x) { return fabsf(x); }
+__device__ __forceinline__ double copysign_t(double x, double y) { return copysign(x, y); }
+__device__ __forceinline__ float copysign_t(float x, float y) { return copysignf(x, y); }
 
 // Householder QR of one chunk's panel (CR x 32).  Thread (k, g) = (t >> 4, t & 15) keeps rows g, g+16, ... of column k in
 // registers, so the 16 row groups of a column sit in ONE wave: the inner products of column J with the wave's own four
@@ -84,21 +131,21 @@ __device__ __forceinline__ double row_ror_add(double x) {
 // parity, published by their owners at the end of the step before): ONE block barrier per column.  Row J of R goes to
 // L.R; the reflector stays unscaled in the registers (scale[J] applied at the end).  Rows beyond the chunk's members are
 // zero on input and stay zero.
-__global__ __launch_bounds__(FT) void k_qr_factor(double* __restrict__ W, long ld, MemberMap mm, int p, int s,
-                                                  double* __restrict__ Vws, double* __restrict__ Tws) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char qr_lds_raw[];
-    FactorLds& L = *reinterpret_cast<FactorLds*>(qr_lds_raw);
-    const int c = blockIdx.x, t = threadIdx.x, k = t >> 4, g = t & 15, w = t >> 6, lane = t & 63;
+template <typename T>
+__device__ __forceinline__ void qr_factor_body(unsigned char* lds_raw, T* __restrict__ W, long ld, const MemberMap& mm, int p,
+                                               int s, int c, T* __restrict__ Vws, T* __restrict__ Tws) {
+    FactorLds<T>& L = *reinterpret_cast<FactorLds<T>*>(lds_raw);
+    const int t = threadIdx.x, k = t >> 4, g = t & 15, w = t >> 6, lane = t & 63;
     int nm = 0;
     for (int q = 0; q < FAN; ++q) nm += member_rb(mm, p, s, c, q) >= 0;
     if (nm == 0 || (nm == 1 && s > 1)) return;  // a lone survivor is already triangular (k_qr_apply skips it too)
 
     for (int e = t; e < CR * QB; e += FT) {   // coalesced: 32 consecutive columns of one row
         const int i = e >> 5, kk = e & 31, q = i >> 5;
-        L.A[i * FLD + kk] = (q < nm) ? W[((long)member_rb(mm, p, s, c, q) * QB + (i & 31)) * ld + (long)p * QB + kk] : 0.0;
+        L.A[i * FLD + kk] = (q < nm) ? W[((long)member_rb(mm, p, s, c, q) * QB + (i & 31)) * ld + (long)p * QB + kk] : T(0);
     }
     __syncthreads();
-    double a[RPT];
+    T a[RPT];
 #pragma unroll
     for (int r = 0; r < RPT; ++r) a[r] = L.A[(g + NG * r) * FLD + k];
     if (k == 0) {
@@ -111,20 +158,20 @@ __global__ __launch_bounds__(FT) void k_qr_factor(double* __restrict__ W, long l
 #pragma unroll
     for (int J = 0; J < QB; ++J) {
         const int cur = J & 1;
-        double vi[RPT];
-        double pk[4] = {0, 0, 0, 0}, pJ[4] = {0, 0, 0, 0};   // four independent accumulation chains each
+        T vi[RPT];
+        T pk[4] = {0, 0, 0, 0}, pJ[4] = {0, 0, 0, 0};   // four independent accumulation chains each
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {   // rows i = g + 16 r > J of column J (r and J are compile-time after unrolling)
             if (NG * r + NG - 1 <= J) {
-                vi[r] = 0.0;
+                vi[r] = T(0);
             } else {
-                const double v = L.col[cur][g + NG * r];
-                vi[r] = (NG * r > J || g + NG * r > J) ? v : 0.0;
+                const T v = L.col[cur][g + NG * r];
+                vi[r] = (NG * r > J || g + NG * r > J) ? v : T(0);
                 pk[r & 3] += vi[r] * a[r];
                 pJ[r & 3] += vi[r] * vi[r];
             }
         }
-        double sk = (pk[0] + pk[1]) + (pk[2] + pk[3]), sJ = (pJ[0] + pJ[1]) + (pJ[2] + pJ[3]);
+        T sk = (pk[0] + pk[1]) + (pk[2] + pk[3]), sJ = (pJ[0] + pJ[1]) + (pJ[2] + pJ[3]);
         // over the column's 16 row groups = one DPP row of the wave
         sk = row_ror_add<8>(sk), sJ = row_ror_add<8>(sJ);
         sk = row_ror_add<4>(sk), sJ = row_ror_add<4>(sJ);
@@ -133,31 +180,27 @@ __global__ __launch_bounds__(FT) void k_qr_factor(double* __restrict__ W, long l
         // dlarfg: H = I - tau v v^T, v = [1; x / (alpha - beta)], beta = -sign(alpha) |(alpha, x)|; with
         // nrm = |(alpha, x)|: tau = (beta - alpha) / beta = 1 + |alpha| / nrm, 1 / (alpha - beta) = sign(alpha) / (|alpha| + nrm)
         // -- one rsqrt and one reciprocal on the step's critical path instead of a sqrt and two divisions
-        const double alpha = L.rowb[cur][J], aJk = L.rowb[cur][k];
-        double beta = alpha, tau = 0.0, scale = 0.0;
-        if (sJ != 0.0) {
-            const double n2 = alpha * alpha + sJ, aa = fabs(alpha);
-            double rn = __builtin_amdgcn_rsq(n2);
-            rn = rn * (1.5 - 0.5 * n2 * rn * rn);          // two Newton steps: full double precision
-            rn = rn * (1.5 - 0.5 * n2 * rn * rn);
-            const double nrm = n2 * rn, den = aa + nrm;
-            double rd = __builtin_amdgcn_rcp(den);
-            rd = rd * (2.0 - den * rd);
-            rd = rd * (2.0 - den * rd);
-            beta = -copysign(nrm, alpha);
-            tau = 1.0 + aa * rn;
-            scale = copysign(rd, alpha);
+        const T alpha = L.rowb[cur][J], aJk = L.rowb[cur][k];
+        T beta = alpha, tau = T(0), scale = T(0);
+        if (sJ != T(0)) {
+            const T n2 = alpha * alpha + sJ, aa = abs_t(alpha);
+            const T rn = rsq_full(n2);
+            const T nrm = n2 * rn, den = aa + nrm;
+            const T rd = rcp_full(den);
+            beta = -copysign_t(nrm, alpha);
+            tau = T(1) + aa * rn;
+            scale = copysign_t(rd, alpha);
         }
-        const double f = tau * (aJk + sk * scale);  // tau v^T A[:, k]
+        const T f = tau * (aJk + sk * scale);  // tau v^T A[:, k]
         if (g == 0) {
-            L.R[J * QB + k] = (k > J) ? aJk - f : (k == J ? beta : 0.0);
+            L.R[J * QB + k] = (k > J) ? aJk - f : (k == J ? beta : T(0));
             if (k == J) {
                 L.tau[J] = tau;
                 L.scale[J] = scale;
             }
         }
         if (k > J) {
-            const double fs = f * scale;
+            const T fs = f * scale;
 #pragma unroll
             for (int r = 0; r < RPT; ++r)
                 if (NG * r + NG - 1 > J) a[r] -= fs * vi[r];
@@ -176,132 +219,172 @@ __global__ __launch_bounds__(FT) void k_qr_factor(double* __restrict__ W, long l
 
     // V: unit lower trapezoidal (column k of the reflectors is rows i > k of the registers, unscaled so far)
     {
-        const double sc = L.scale[k];
+        const T sc = L.scale[k];
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
             const int i = g + NG * r;
-            L.A[i * FLD + k] = (i > k) ? a[r] * sc : (i == k ? 1.0 : 0.0);
+            L.A[i * FLD + k] = (i > k) ? a[r] * sc : (i == k ? T(1) : T(0));
         }
     }
     __syncthreads();
     // G = V^T V on the MFMA: waves 0..3 take one 16x16 tile each
     if (w < 4) {
         const int fr = lane & 15, fk = lane >> 4, jt = w >> 1, ct = w & 1;
-        d4 acc = {0, 0, 0, 0};
+        typename Mf<T>::acc_t acc = {0, 0, 0, 0};
         for (int st = 0; st < CR / 4; ++st) {
-            const double va = L.A[(4 * st + fk) * FLD + jt * 16 + fr];
-            const double vb = L.A[(4 * st + fk) * FLD + ct * 16 + fr];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va, vb, acc, 0, 0, 0);
+            const T va = L.A[(4 * st + fk) * FLD + jt * 16 + fr];
+            const T vb = L.A[(4 * st + fk) * FLD + ct * 16 + fr];
+            acc = Mf<T>::mfma(va, vb, acc);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) L.G[(jt * 16 + fk + 4 * r) * QB + ct * 16 + fr] = acc[r];
+        for (int r = 0; r < 4; ++r) L.G[(jt * 16 + Mf<T>::row(fk, r)) * QB + ct * 16 + fr] = acc[r];
     }
     __syncthreads();
     // dlarft (forward, columnwise): T[0:J, J] = -tau_J T[0:J, 0:J] (V^T V)[0:J, J]; lane j keeps row j of T
-    double* Tg = Tws + (long)c * QB * QB;
+    T* Tg = Tws + (long)c * QB * QB;
     if (t < QB) {
-        double trow[QB];
+        T trow[QB];
 #pragma unroll
         for (int J = 0; J < QB; ++J) {
-            double acc = 0.0;
+            T acc = T(0);
 #pragma unroll
             for (int l = 0; l < J; ++l) acc += trow[l] * L.G[l * QB + J];   // trow[l] = 0 for l < t
-            const double tj = L.tau[J];
-            trow[J] = (t < J) ? -tj * acc : (t == J ? tj : 0.0);
+            const T tj = L.tau[J];
+            trow[J] = (t < J) ? -tj * acc : (t == J ? tj : T(0));
         }
 #pragma unroll
         for (int J = 0; J < QB; ++J) Tg[t * QB + J] = trow[J];
     }
     // V to the workspace, R (upper, zero below) to the first member: coalesced from LDS
-    double* Vg = Vws + (long)c * CR * QB;
+    T* Vg = Vws + (long)c * CR * QB;
     for (int e = t; e < CR * QB; e += FT) Vg[e] = L.A[(e >> 5) * FLD + (e & 31)];
     for (int e = t; e < QB * QB; e += FT)
         W[((long)member_rb(mm, p, s, c, 0) * QB + (e >> 5)) * ld + (long)p * QB + (e & 31)] = L.R[e];
+}
+
+template <typename T>
+__global__ __launch_bounds__(FT) void k_qr_factor(T* __restrict__ W, long ld, MemberMap mm, int p, int s,
+                                                  T* __restrict__ Vws, T* __restrict__ Tws) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char qr_lds_raw[];
+    qr_factor_body<T>(qr_lds_raw, W, ld, mm, p, s, blockIdx.x, Vws, Tws);
 }
 
 // C <- (I - V T V^T)^T C = C - V (T^T (V^T C)) on the chunk's rows of 64 trailing columns per block, 16 per wave.  The
 // wave keeps its 256 x 16 slab of C in registers in the MFMA's B-operand layout (lane (fr, fk) holds C[4s + fk][fr]),
 // which is also the accumulator layout of the 16-row tile s / 4 (row fk + 4 (s % 4)): the last product accumulates
 // straight into the slab.
-__global__ __launch_bounds__(256) void k_qr_apply(double* __restrict__ W, long ld, MemberMap mm, int p, int s,
-                                                  const double* __restrict__ Vws, const double* __restrict__ Tws,
-                                                  int col0, int ncols) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char qr_lds_raw[];
-    double* sV = reinterpret_cast<double*>(qr_lds_raw);  // CR x VLD
-    double* sT = sV + CR * VLD;                           // 32 x VLD
-    double* sWall = sT + QB * VLD;                        // per wave: 32 x 17
-    const int c = blockIdx.x, t = threadIdx.x, w = t >> 6, lane = t & 63, fr = lane & 15, fk = lane >> 4;
+// fp32 build: the slab's element st of a lane with l >> 4 == fk is row 16 (st / 4) + Mf::row(fk, st % 4) -- the order in
+// which the f32 accumulator holds a 16-row tile -- and the first product walks V in that order too (a sum over rows does
+// not care which lane group brings which row).
+// NT threads: NT / 64 waves, 16 columns each; cg: the block's column group (NT / 4 columns).
+template <typename T, int NT>
+__device__ __forceinline__ void qr_apply_body(unsigned char* lds_raw, T* __restrict__ W, long ld, const MemberMap& mm, int p,
+                                              int s, int c, int cg, const T* __restrict__ Vws, const T* __restrict__ Tws,
+                                              int col0, int ncols) {
+    constexpr int VLD = Mf<T>::VLD;
+    T* sV = reinterpret_cast<T*>(lds_raw);     // CR x VLD
+    T* sT = sV + CR * VLD;                      // 32 x VLD
+    T* sWall = sT + QB * VLD;                   // per wave: 32 x 17
+    const int t = threadIdx.x, w = t >> 6, lane = t & 63, fr = lane & 15, fk = lane >> 4;
     int nm = 0;
     for (int q = 0; q < FAN; ++q) nm += member_rb(mm, p, s, c, q) >= 0;
     if (nm == 0 || (nm == 1 && s > 1)) return;
-    const double* Vg = Vws + (long)c * CR * QB;
-    const double* Tg = Tws + (long)c * QB * QB;
-    for (int e = t; e < CR * QB; e += 256) sV[(e >> 5) * VLD + (e & 31)] = Vg[e];
-    for (int e = t; e < QB * QB; e += 256) sT[(e >> 5) * VLD + (e & 31)] = Tg[e];
+    const T* Vg = Vws + (long)c * CR * QB;
+    const T* Tg = Tws + (long)c * QB * QB;
+    for (int e = t; e < CR * QB; e += NT) sV[(e >> 5) * VLD + (e & 31)] = Vg[e];
+    for (int e = t; e < QB * QB; e += NT) sT[(e >> 5) * VLD + (e & 31)] = Tg[e];
 
-    const int cw = blockIdx.y * 64 + w * 16;       // this wave's first column, relative to col0
+    const int cw = cg * (NT / 4) + w * 16;         // this wave's first column, relative to col0
     const bool active = cw < ncols;                // ncols is a multiple of 16
     const long col = col0 + (active ? cw : 0) + fr;
-    double cs[CR / 4];
+    T cs[CR / 4];
 #pragma unroll
     for (int st = 0; st < CR / 4; ++st) {
-        const int i = 4 * st + fk, q = i >> 5;
-        cs[st] = (q < nm) ? W[((long)member_rb(mm, p, s, c, q) * QB + (i & 31)) * ld + col] : 0.0;
+        const int i = 16 * (st >> 2) + Mf<T>::row(fk, st & 3), q = i >> 5;
+        cs[st] = (q < nm) ? W[((long)member_rb(mm, p, s, c, q) * QB + (i & 31)) * ld + col] : T(0);
     }
     __syncthreads();
 
     // W1 = V^T C  (32 x 16)
-    d4 w1[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    typename Mf<T>::acc_t w1[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
     for (int st = 0; st < CR / 4; ++st) {
-        w1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(sV[(4 * st + fk) * VLD + fr], cs[st], w1[0], 0, 0, 0);
-        w1[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(sV[(4 * st + fk) * VLD + 16 + fr], cs[st], w1[1], 0, 0, 0);
+        const int i = 16 * (st >> 2) + Mf<T>::row(fk, st & 3);
+        w1[0] = Mf<T>::mfma(sV[i * VLD + fr], cs[st], w1[0]);
+        w1[1] = Mf<T>::mfma(sV[i * VLD + 16 + fr], cs[st], w1[1]);
     }
-    double* sW = sWall + w * (QB * 17);
+    T* sW = sWall + w * (QB * 17);
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sW[(jt * 16 + fk + 4 * r) * 17 + fr] = w1[jt][r];
+        for (int r = 0; r < 4; ++r) sW[(jt * 16 + Mf<T>::row(fk, r)) * 17 + fr] = w1[jt][r];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // W2 = T^T W1: D[j][n] = sum_l T[l][j] W1[l][n]
-    d4 w2[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    typename Mf<T>::acc_t w2[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
     for (int st = 0; st < QB / 4; ++st) {
-        const double b = sW[(4 * st + fk) * 17 + fr];
-        w2[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(sT[(4 * st + fk) * VLD + fr], b, w2[0], 0, 0, 0);
-        w2[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(sT[(4 * st + fk) * VLD + 16 + fr], b, w2[1], 0, 0, 0);
+        const T b = sW[(4 * st + fk) * 17 + fr];
+        w2[0] = Mf<T>::mfma(sT[(4 * st + fk) * VLD + fr], b, w2[0]);
+        w2[1] = Mf<T>::mfma(sT[(4 * st + fk) * VLD + 16 + fr], b, w2[1]);
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sW[(jt * 16 + fk + 4 * r) * 17 + fr] = w2[jt][r];
+        for (int r = 0; r < 4; ++r) sW[(jt * 16 + Mf<T>::row(fk, r)) * 17 + fr] = w2[jt][r];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    double b2[QB / 4];
+    T b2[QB / 4];
 #pragma unroll
     for (int st = 0; st < QB / 4; ++st) b2[st] = sW[(4 * st + fk) * 17 + fr];
     // C -= V W2, 16 rows at a time
 #pragma unroll
     for (int it = 0; it < CR / 16; ++it) {
-        d4 acc = {cs[4 * it], cs[4 * it + 1], cs[4 * it + 2], cs[4 * it + 3]};
+        typename Mf<T>::acc_t acc = {cs[4 * it], cs[4 * it + 1], cs[4 * it + 2], cs[4 * it + 3]};
 #pragma unroll
         for (int st = 0; st < QB / 4; ++st)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-sV[(it * 16 + fr) * VLD + 4 * st + fk], b2[st], acc, 0, 0, 0);
+            acc = Mf<T>::mfma(-sV[(it * 16 + fr) * VLD + 4 * st + fk], b2[st], acc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) cs[4 * it + r] = acc[r];
     }
     if (!active) return;
 #pragma unroll
     for (int st = 0; st < CR / 4; ++st) {
-        const int i = 4 * st + fk, q = i >> 5;
+        const int i = 16 * (st >> 2) + Mf<T>::row(fk, st & 3), q = i >> 5;
         if (q < nm) W[((long)member_rb(mm, p, s, c, q) * QB + (i & 31)) * ld + col] = cs[st];
     }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void k_qr_apply(T* __restrict__ W, long ld, MemberMap mm, int p, int s,
+                                                  const T* __restrict__ Vws, const T* __restrict__ Tws,
+                                                  int col0, int ncols) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char qr_lds_raw[];
+    qr_apply_body<T, 256>(qr_lds_raw, W, ld, mm, p, s, blockIdx.x, blockIdx.y, Vws, Tws, col0, ncols);
+}
+
+// One launch for two things that do not depend on each other: the trailing update of tree level `sa` (reads the
+// reflectors of that level, touches the columns behind the panel) and the panel factorisation of the NEXT level `sf` (touches the panel's
+// columns of the level-`sa` survivors, which k_qr_factor of level `sa` left final).  Blocks [0, nchf) factorise -- first in
+// the dispatch order, they are the longer ones --, the rest apply: block nchf + cg * ncha + c is chunk c, column group cg.
+template <typename T>
+__global__ __launch_bounds__(FT) void k_qr_apply_factor(T* __restrict__ W, long ld, MemberMap mm, int p, int sa, int ncha,
+                                                        const T* __restrict__ Va, const T* __restrict__ Ta, int col0,
+                                                        int ncols, int sf, int nchf, T* __restrict__ Vf, T* __restrict__ Tf) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char qr_lds_raw[];
+    const int b = blockIdx.x;
+    if (b < nchf) {
+        qr_factor_body<T>(qr_lds_raw, W, ld, mm, p, sf, b, Vf, Tf);
+    } else {
+        const int a = b - nchf;
+        qr_apply_body<T, FT>(qr_lds_raw, W, ld, mm, p, sa, a % ncha, a / ncha, Va, Ta, col0, ncols);
+    }
+}
+
 // dst[j][i] = src[i][j], i < nr, j < nc (tile transpose through LDS)
-__global__ __launch_bounds__(256) void k_copy_t(double* __restrict__ dst, long ldd, const double* __restrict__ src,
+template <typename DT>
+__global__ __launch_bounds__(256) void k_copy_t(DT* __restrict__ dst, long ldd, const double* __restrict__ src,
                                                 long lds, int nr, int nc) {
     __shared__ double tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -313,7 +396,7 @@ __global__ __launch_bounds__(256) void k_copy_t(double* __restrict__ dst, long l
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         const int j = j0 + r, i = i0 + tx;
-        if (i < nr && j < nc) dst[(long)j * ldd + i] = tile[tx][r];
+        if (i < nr && j < nc) dst[(long)j * ldd + i] = (DT)tile[tx][r];
     }
 }
 
@@ -415,20 +498,29 @@ __global__ __launch_bounds__(256) void k_trsm_upper(double* __restrict__ W, long
 
 struct QrPlan {
     int rows = 0, cols = 0, Mp = 0, ld = 0, nrb = 0, ncb = 0;
-    double *W = nullptr, *Vws = nullptr, *Tws = nullptr;
+    int f32 = 0;                                  // element type of W, Vws, Tws: double or float
+    int ws_chunks = 0;
+    void *W = nullptr, *Vws = nullptr, *Tws = nullptr;
+    template <typename T> T* vws(int lvl) const { return static_cast<T*>(Vws) + (size_t)(lvl & 1) * ws_chunks * CR * QB; }
+    template <typename T> T* tws(int lvl) const { return static_cast<T*>(Tws) + (size_t)(lvl & 1) * ws_chunks * QB * QB; }
+    size_t es() const { return f32 ? sizeof(float) : sizeof(double); }
+    size_t bytes() const { return es() * (size_t)Mp * ld; }
+    template <typename T> T* w() const { return static_cast<T*>(W); }
 };
 
-int qr_plan_alloc(pnmol_ctx* ctx, int rows, int cols, QrPlan* pl) {
+int qr_plan_alloc(pnmol_ctx* ctx, int rows, int cols, QrPlan* pl, int f32 = 0) {
     pl->rows = rows;
     pl->cols = cols;
+    pl->f32 = f32;
     pl->ld = (cols + QB - 1) / QB * QB;
     pl->Mp = (std::max(rows, pl->ld) + QB - 1) / QB * QB;
     pl->nrb = pl->Mp / QB;
     pl->ncb = pl->ld / QB;
     const int maxchunks = (pl->nrb + FAN - 1) / FAN;
-    QCHECK(ctx, hipMalloc(&pl->W, sizeof(double) * (size_t)pl->Mp * pl->ld));
-    QCHECK(ctx, hipMalloc(&pl->Vws, sizeof(double) * (size_t)maxchunks * CR * QB));
-    QCHECK(ctx, hipMalloc(&pl->Tws, sizeof(double) * (size_t)maxchunks * QB * QB));
+    QCHECK(ctx, hipMalloc(&pl->W, pl->bytes()));
+    pl->ws_chunks = maxchunks;   // two sets of reflector workspaces, by tree-level parity (k_qr_apply_factor)
+    QCHECK(ctx, hipMalloc(&pl->Vws, 2 * pl->es() * (size_t)maxchunks * CR * QB));
+    QCHECK(ctx, hipMalloc(&pl->Tws, 2 * pl->es() * (size_t)maxchunks * QB * QB));
     return 0;
 }
 
@@ -439,13 +531,49 @@ void qr_plan_free(QrPlan* pl) {
     *pl = QrPlan();
 }
 
-constexpr size_t kFactorLds = sizeof(FactorLds);
-constexpr size_t kApplyLds = sizeof(double) * (CR * VLD + QB * VLD + 4 * QB * 17);
+template <typename T> constexpr size_t kFactorLds = sizeof(FactorLds<T>);
+template <typename T, int NT> constexpr size_t kApplyLds = sizeof(T) * (CR * Mf<T>::VLD + QB * Mf<T>::VLD + (NT / 64) * QB * 17);
+template <typename T> constexpr size_t kFusedLds = kFactorLds<T> > kApplyLds<T, FT> ? kFactorLds<T> : kApplyLds<T, FT>;
+
+template <typename T>
+int qr_configure_t(pnmol_ctx* ctx) {
+    QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_factor<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFactorLds<T>));
+    QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_apply<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kApplyLds<T, 256>));
+    QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_apply_factor<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds<T>));
+    return 0;
+}
 
 int qr_configure(pnmol_ctx* ctx) {   // attributes are per function and device; cheap to repeat
-    QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_factor, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFactorLds));
-    QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kApplyLds));
-    return 0;
+    if (int rc = qr_configure_t<double>(ctx)) return rc;
+    return qr_configure_t<float>(ctx);
+}
+
+// The tree levels of one panel: factor(1); [apply(s) + factor(8 s)] in one launch per further level; apply(last level).
+// PNMOL_QR_FUSE=0: factor and apply of a level one after the other (the A/B switch; same arithmetic, same results).
+template <typename T>
+void qr_launch_panel(pnmol_ctx* ctx, const QrPlan& pl, const MemberMap& mm, int p, int ntrail, bool fuse) {
+    T* W = pl.w<T>();
+    const long ld = pl.ld;
+    const int col0 = (p + 1) * QB;
+    constexpr size_t apply_lds = kApplyLds<T, 256>;
+    int lvl = 0, s_prev = 0, nch_prev = 0;
+    for (int s = 1;; s *= FAN, ++lvl) {
+        const int nmem = (mm.cnt + s - 1) / s, nch = (nmem + FAN - 1) / FAN;
+        if (lvl == 0 || ntrail <= 0 || !fuse) {
+            hipLaunchKernelGGL(k_qr_factor<T>, dim3(nch), dim3(FT), kFactorLds<T>, ctx->stream, W, ld, mm, p, s, pl.vws<T>(lvl),
+                               pl.tws<T>(lvl));
+        } else {
+            const int ncg = (ntrail + FT / 4 - 1) / (FT / 4);
+            hipLaunchKernelGGL(k_qr_apply_factor<T>, dim3(nch + nch_prev * ncg), dim3(FT), kFusedLds<T>, ctx->stream, W, ld, mm,
+                               p, s_prev, nch_prev, pl.vws<T>(lvl - 1), pl.tws<T>(lvl - 1), col0, ntrail, s, nch,
+                               pl.vws<T>(lvl), pl.tws<T>(lvl));
+        }
+        if (ntrail > 0 && (!fuse || nch == 1))
+            hipLaunchKernelGGL(k_qr_apply<T>, dim3(nch, (ntrail + 63) / 64), dim3(256), apply_lds, ctx->stream, W, ld, mm,
+                               p, s, pl.vws<T>(lvl), pl.tws<T>(lvl), col0, ntrail);
+        s_prev = s, nch_prev = nch;
+        if (nch == 1) break;
+    }
 }
 
 // R factor of the padded work matrix, in place (upper triangle of W's leading ld x ld block).  tri_bot0 > 0: the matrix
@@ -455,6 +583,7 @@ int qr_configure(pnmol_ctx* ctx) {   // attributes are per function and device; 
 // panel p has the dense rows from its diagonal on and the triangle's row blocks 0..p; once the dense rows are used up
 // (p >= stacked_tri) the diagonal block is in the triangle, whose blocks p - stacked_tri .. p carry the panel.
 int qr_inplace(pnmol_ctx* ctx, const QrPlan& pl, int tri_bot0 = 0, int stacked_tri = 0) {
+    const bool fuse = !(std::getenv("PNMOL_QR_FUSE") && std::atoi(std::getenv("PNMOL_QR_FUSE")) == 0);
     for (int p = 0; p < pl.ncb; ++p) {
         MemberMap mm;
         if (stacked_tri > 0) {
@@ -476,15 +605,8 @@ int qr_inplace(pnmol_ctx* ctx, const QrPlan& pl, int tri_bot0 = 0, int stacked_t
             mm.bot0 = 0;
         }
         const int ntrail = pl.ld - (p + 1) * QB;
-        for (int s = 1;; s *= FAN) {
-            const int nmem = (mm.cnt + s - 1) / s, nch = (nmem + FAN - 1) / FAN;
-            hipLaunchKernelGGL(k_qr_factor, dim3(nch), dim3(FT), kFactorLds, ctx->stream, pl.W, (long)pl.ld, mm, p, s,
-                               pl.Vws, pl.Tws);
-            if (ntrail > 0)
-                hipLaunchKernelGGL(k_qr_apply, dim3(nch, (ntrail + 63) / 64), dim3(256), kApplyLds, ctx->stream, pl.W,
-                                   (long)pl.ld, mm, p, s, pl.Vws, pl.Tws, (p + 1) * QB, ntrail);
-            if (nch == 1) break;
-        }
+        if (pl.f32) qr_launch_panel<float>(ctx, pl, mm, p, ntrail, fuse);
+        else qr_launch_panel<double>(ctx, pl, mm, p, ntrail, fuse);
     }
     QCHECK(ctx, hipGetLastError());
     return 0;
@@ -532,8 +654,8 @@ int pnmol_qr_r(pnmol_ctx* ctx, const double* A, int rows, int cols, double* R) {
     int rc = 0;
     do {
         if (hipMalloc(&dR, sizeof(double) * (size_t)cols * cols) != hipSuccess) { rc = -4; break; }
-        if (hipMemsetAsync(pl.W, 0, sizeof(double) * (size_t)pl.Mp * pl.ld, ctx->stream) != hipSuccess) { rc = -2; break; }
-        if (hipMemcpy2DAsync(pl.W, sizeof(double) * pl.ld, A, sizeof(double) * cols, sizeof(double) * cols, rows,
+        if (hipMemsetAsync(pl.w<double>(), 0, sizeof(double) * (size_t)pl.Mp * pl.ld, ctx->stream) != hipSuccess) { rc = -2; break; }
+        if (hipMemcpy2DAsync(pl.w<double>(), sizeof(double) * pl.ld, A, sizeof(double) * cols, sizeof(double) * cols, rows,
                              hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = -2; break; }
         {
             QrTimer tm(ctx->stream);
@@ -541,7 +663,7 @@ int pnmol_qr_r(pnmol_ctx* ctx, const double* A, int rows, int cols, double* R) {
             tm.stop();
         }
         if (rc) break;
-        hipLaunchKernelGGL(k_qr_block, dim3((cols + 31) / 32, (cols + 7) / 8), dim3(32, 8), 0, ctx->stream, pl.W,
+        hipLaunchKernelGGL(k_qr_block, dim3((cols + 31) / 32, (cols + 7) / 8), dim3(32, 8), 0, ctx->stream, pl.w<double>(),
                            (long)pl.ld, 0, 0, cols, cols, dR, 0, 1, 1);
         if (hipMemcpyAsync(R, dR, sizeof(double) * (size_t)cols * cols, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { rc = -2; break; }
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = -2; break; }
@@ -595,27 +717,27 @@ int sqrt_update(pnmol_ctx* ctx, const double* H, int m, int D, const double* C, 
     if (int rc = dC.upload(ctx, C, (size_t)D * D)) return rc;
     if (E) if (int rc = dE.upload(ctx, E, (size_t)m * m)) return rc;
     if (int rc = dOut.alloc((size_t)D * D)) return rc;
-    QCHECK(ctx, hipMemsetAsync(pl.W, 0, sizeof(double) * (size_t)pl.Mp * pl.ld, ctx->stream));
+    QCHECK(ctx, hipMemsetAsync(pl.w<double>(), 0, sizeof(double) * (size_t)pl.Mp * pl.ld, ctx->stream));
     // [[C^T H^T, C^T], [E^T, 0]]
-    hipLaunchKernelGGL(k_atbt, tiles(m, D), dim3(256), 0, ctx->stream, pl.W, (long)pl.ld, dC.p, (long)D, dH.p, (long)D, D, m, D);
-    hipLaunchKernelGGL(k_copy_t, tiles(D, D), dim3(256), 0, ctx->stream, pl.W + m, (long)pl.ld, dC.p, (long)D, D, D);
+    hipLaunchKernelGGL(k_atbt, tiles(m, D), dim3(256), 0, ctx->stream, pl.w<double>(), (long)pl.ld, dC.p, (long)D, dH.p, (long)D, D, m, D);
+    hipLaunchKernelGGL(k_copy_t<double>, tiles(D, D), dim3(256), 0, ctx->stream, pl.w<double>() + m, (long)pl.ld, dC.p, (long)D, D, D);
     if (E)
-        hipLaunchKernelGGL(k_copy_t, tiles(m, m), dim3(256), 0, ctx->stream, pl.W + (long)D * pl.ld, (long)pl.ld, dE.p, (long)m, m, m);
+        hipLaunchKernelGGL(k_copy_t<double>, tiles(m, m), dim3(256), 0, ctx->stream, pl.w<double>() + (long)D * pl.ld, (long)pl.ld, dE.p, (long)m, m, m);
     if (int rc = run_qr_timed(ctx, pl)) return rc;
     const dim3 tb(32, 8);
     if (Sl) {   // R1^T
-        hipLaunchKernelGGL(k_qr_block, dim3((m + 31) / 32, (m + 7) / 8), tb, 0, ctx->stream, pl.W, (long)pl.ld, 0, 0, m, m, dOut.p, 1, 1, 1);
+        hipLaunchKernelGGL(k_qr_block, dim3((m + 31) / 32, (m + 7) / 8), tb, 0, ctx->stream, pl.w<double>(), (long)pl.ld, 0, 0, m, m, dOut.p, 1, 1, 1);
         QCHECK(ctx, hipMemcpyAsync(Sl, dOut.p, sizeof(double) * (size_t)m * m, hipMemcpyDeviceToHost, ctx->stream));
     }
     if (C_new) {   // R3^T
         QCHECK(ctx, hipStreamSynchronize(ctx->stream));
-        hipLaunchKernelGGL(k_qr_block, dim3((D + 31) / 32, (D + 7) / 8), tb, 0, ctx->stream, pl.W, (long)pl.ld, m, m, D, D, dOut.p, 1, 1, 1);
+        hipLaunchKernelGGL(k_qr_block, dim3((D + 31) / 32, (D + 7) / 8), tb, 0, ctx->stream, pl.w<double>(), (long)pl.ld, m, m, D, D, dOut.p, 1, 1, 1);
         QCHECK(ctx, hipMemcpyAsync(C_new, dOut.p, sizeof(double) * (size_t)D * D, hipMemcpyDeviceToHost, ctx->stream));
     }
     if (gain) {   // (R1^-1 R2)^T
         QCHECK(ctx, hipStreamSynchronize(ctx->stream));
-        hipLaunchKernelGGL(k_trsm_upper, dim3((D + 31) / 32), dim3(256), 0, ctx->stream, pl.W, (long)pl.ld, m, m, D);
-        hipLaunchKernelGGL(k_qr_block, dim3((D + 31) / 32, (m + 7) / 8), tb, 0, ctx->stream, pl.W, (long)pl.ld, 0, m, m, D, dOut.p, 1, 0, 0);
+        hipLaunchKernelGGL(k_trsm_upper, dim3((D + 31) / 32), dim3(256), 0, ctx->stream, pl.w<double>(), (long)pl.ld, m, m, D);
+        hipLaunchKernelGGL(k_qr_block, dim3((D + 31) / 32, (m + 7) / 8), tb, 0, ctx->stream, pl.w<double>(), (long)pl.ld, 0, m, m, D, dOut.p, 1, 0, 0);
         QCHECK(ctx, hipMemcpyAsync(gain, dOut.p, sizeof(double) * (size_t)D * m, hipMemcpyDeviceToHost, ctx->stream));
     }
     QCHECK(ctx, hipGetLastError());
@@ -640,13 +762,13 @@ int pnmol_sqrt_propagate_cholesky_factor(pnmol_ctx* ctx, const double* S1, int n
     if (int rc = d1.upload(ctx, S1, (size_t)n * k1)) return rc;
     if (S2) if (int rc = d2.upload(ctx, S2, (size_t)n * k2)) return rc;
     if (int rc = dOut.alloc((size_t)n * n)) return rc;
-    QCHECK(ctx, hipMemsetAsync(pl.W, 0, sizeof(double) * (size_t)pl.Mp * pl.ld, ctx->stream));
+    QCHECK(ctx, hipMemsetAsync(pl.w<double>(), 0, sizeof(double) * (size_t)pl.Mp * pl.ld, ctx->stream));
     // vstack(S1^T, S2^T), base/sqrt.py:11
-    hipLaunchKernelGGL(k_copy_t, tiles(k1, n), dim3(256), 0, ctx->stream, pl.W, (long)pl.ld, d1.p, (long)k1, n, k1);
+    hipLaunchKernelGGL(k_copy_t<double>, tiles(k1, n), dim3(256), 0, ctx->stream, pl.w<double>(), (long)pl.ld, d1.p, (long)k1, n, k1);
     if (S2)
-        hipLaunchKernelGGL(k_copy_t, tiles(k2, n), dim3(256), 0, ctx->stream, pl.W + (long)k1 * pl.ld, (long)pl.ld, d2.p, (long)k2, n, k2);
+        hipLaunchKernelGGL(k_copy_t<double>, tiles(k2, n), dim3(256), 0, ctx->stream, pl.w<double>() + (long)k1 * pl.ld, (long)pl.ld, d2.p, (long)k2, n, k2);
     if (int rc = run_qr_timed(ctx, pl)) return rc;
-    hipLaunchKernelGGL(k_qr_block, dim3((n + 31) / 32, (n + 7) / 8), dim3(32, 8), 0, ctx->stream, pl.W, (long)pl.ld, 0, 0, n, n, dOut.p, 1, 1, 1);
+    hipLaunchKernelGGL(k_qr_block, dim3((n + 31) / 32, (n + 7) / 8), dim3(32, 8), 0, ctx->stream, pl.w<double>(), (long)pl.ld, 0, 0, n, n, dOut.p, 1, 1, 1);
     QCHECK(ctx, hipMemcpyAsync(chol_nn, dOut.p, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost, ctx->stream));
     QCHECK(ctx, hipGetLastError());
     QCHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -705,7 +827,8 @@ __global__ void k_sq_mean(double* __restrict__ mp, const double* __restrict__ me
 }
 
 // out[i][j] = sum_{k >= i} R[i][k] Hraw[j][k] p[k % n]  (= (H Cl-)^T with Cl- = R^T, H = Hraw P): 32x32 tile per block
-__global__ __launch_bounds__(256) void k_rht(double* __restrict__ out, long ldo, const double* __restrict__ R, long ldr,
+template <typename OT, typename RT>
+__global__ __launch_bounds__(256) void k_rht(OT* __restrict__ out, long ldo, const RT* __restrict__ R, long ldr,
                                              const double* __restrict__ Hraw, int D, int m, SqConst kc) {
     __shared__ double sA[32][33], sH[32][33];
     const int t = threadIdx.x, w = t >> 6, lane = t & 63, fr = lane & 15, fk = lane >> 4, wr = w >> 1, wc = w & 1;
@@ -716,7 +839,7 @@ __global__ __launch_bounds__(256) void k_rht(double* __restrict__ out, long ldo,
         const double pk = kc.p[k % kc.n];
         for (int r = ty; r < 32; r += 8) {
             const int i = i0 + r, j = j0 + r;
-            sA[r][tx] = (i < D && k < D && k >= i) ? R[(long)i * ldr + k] : 0.0;
+            sA[r][tx] = (i < D && k < D && k >= i) ? (double)R[(long)i * ldr + k] : 0.0;
             sH[r][tx] = (j < m && k < D) ? Hraw[(long)j * D + k] * pk : 0.0;
         }
         __syncthreads();
@@ -728,20 +851,22 @@ __global__ __launch_bounds__(256) void k_rht(double* __restrict__ out, long ldo,
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int i = i0 + wr * 16 + fk + 4 * r, j = j0 + wc * 16 + fr;
-        if (i < D && j < m) out[(long)i * ldo + j] = acc[r];
+        if (i < D && j < m) out[(long)i * ldo + j] = (OT)acc[r];
     }
 }
 
 // W2[i][c0 + k] = R[i][k] (upper triangle, zero below)
-__global__ void k_sq_fill_r(double* __restrict__ W2, long ld2, int c0, const double* __restrict__ R, long ldr, int D) {
+template <typename WT>
+__global__ void k_sq_fill_r(WT* __restrict__ W2, long ld2, int c0, const WT* __restrict__ R, long ldr, int D) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y * blockDim.y + threadIdx.y;
     if (k >= D || i >= D) return;
-    W2[(long)i * ld2 + c0 + k] = (k >= i) ? R[(long)i * ldr + k] : 0.0;
+    W2[(long)i * ld2 + c0 + k] = (k >= i) ? R[(long)i * ldr + k] : WT(0);
 }
 
 // out[i][j] = sum_k T1[k][i] Hraw[j][k] p[k % n]  (= (H T1)^T, H = Hraw P, T1 = A Pinv Cl lower triangular up to the n x n
 // point blocks when Cl is (`tri`): T1[k][i] = 0 for i >= k + n, so k starts a tile before i0): 32x32 tile per block
-__global__ __launch_bounds__(256) void k_sq_tht(double* __restrict__ out, long ldo, const double* __restrict__ T1,
+template <typename OT>
+__global__ __launch_bounds__(256) void k_sq_tht(OT* __restrict__ out, long ldo, const double* __restrict__ T1,
                                                 const double* __restrict__ Hraw, int D, int m, SqConst kc, int tri) {
     __shared__ double sA[32][33], sH[32][33];
     const int t = threadIdx.x, w = t >> 6, lane = t & 63, fr = lane & 15, fk = lane >> 4, wr = w >> 1, wc = w & 1;
@@ -762,15 +887,16 @@ __global__ __launch_bounds__(256) void k_sq_tht(double* __restrict__ out, long l
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int i = i0 + wr * 16 + fk + 4 * r, j = j0 + wc * 16 + fr;
-        if (i < D && j < m) out[(long)i * ldo + j] = acc[r];
+        if (i < D && j < m) out[(long)i * ldo + j] = (OT)acc[r];
     }
 }
 
 // dst[i][c] = src[i][c] for c >= i, 0 below the diagonal (what a finished QR leaves below R is not R)
-__global__ void k_sq_copy_upper(double* __restrict__ dst, long ldd, const double* __restrict__ src, long lds, int n) {
+template <typename WT>
+__global__ void k_sq_copy_upper(WT* __restrict__ dst, long ldd, const WT* __restrict__ src, long lds, int n) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y * blockDim.y + threadIdx.y;
     if (c >= n || i >= n) return;
-    dst[(long)i * ldd + c] = (c >= i) ? src[(long)i * lds + c] : 0.0;
+    dst[(long)i * ldd + c] = (c >= i) ? src[(long)i * lds + c] : WT(0);
 }
 
 // z = Hraw P mp + shift (white.py:169-186): one wave per row
@@ -787,7 +913,8 @@ __global__ __launch_bounds__(256) void k_sq_gemv_z(double* __restrict__ z, const
 
 // y = R1^-T z and x = R1c^-1 z (R1c = R1 with rows flipped to a positive diagonal; white.py:125 solves with Sl^T = R1),
 // R1 = W[0:m, 0:m] upper.  norms = {|y|^2, |x|^2}.  One block; 32-wide diagonal solves by one wave in registers.
-__global__ __launch_bounds__(1024) void k_sq_trsv(const double* __restrict__ W, long ld, int m,
+template <typename WT>
+__global__ __launch_bounds__(1024) void k_sq_trsv(const WT* __restrict__ W, long ld, int m,
                                                   const double* __restrict__ z, double* __restrict__ y,
                                                   double* __restrict__ x, double* __restrict__ norms) {
     extern __shared__ __attribute__((aligned(16))) unsigned char qr_lds_raw[];
@@ -803,7 +930,7 @@ __global__ __launch_bounds__(1024) void k_sq_trsv(const double* __restrict__ W, 
         __syncthreads();
         {
             const int r = t >> 5, c = t & 31, gi = b * 32 + r, gj = b * 32 + c;
-            tile[r * 33 + c] = (gi < m && gj < m) ? W[(long)gi * ld + gj] : (gi == gj ? 1.0 : 0.0);
+            tile[r * 33 + c] = (gi < m && gj < m) ? (double)W[(long)gi * ld + gj] : (gi == gj ? 1.0 : 0.0);
         }
         __syncthreads();
         if (t < 64) {
@@ -822,7 +949,7 @@ __global__ __launch_bounds__(1024) void k_sq_trsv(const double* __restrict__ W, 
 #pragma unroll 8
             for (int k = 0; k < 32; ++k) {
                 const int gk = b * 32 + k;
-                if (gk < m) a += W[(long)gk * ld + i] * ss[gk];
+                if (gk < m) a += (double)W[(long)gk * ld + i] * ss[gk];
             }
             sv[i] -= a;
         }
@@ -839,16 +966,16 @@ __global__ __launch_bounds__(1024) void k_sq_trsv(const double* __restrict__ W, 
         const int r = t >> 5, l32 = t & 31, gi = b * 32 + r;
         double a = 0.0;
         if (gi < m)
-            for (int k = (b + 1) * 32 + l32; k < m; k += 32) a += W[(long)gi * ld + k] * ss[k];
+            for (int k = (b + 1) * 32 + l32; k < m; k += 32) a += (double)W[(long)gi * ld + k] * ss[k];
         for (int o = 16; o > 0; o >>= 1) a += __shfl_xor(a, o);
         if (l32 == 0) {
             double rhs = 0.0;
-            if (gi < m) rhs = (W[(long)gi * ld + gi] < 0.0 ? -z[gi] : z[gi]) - a;
+            if (gi < m) rhs = (W[(long)gi * ld + gi] < WT(0) ? -z[gi] : z[gi]) - a;
             red[r] = rhs;
         }
         {
             const int c = t & 31, gj = b * 32 + c;
-            tile[r * 33 + c] = (gi < m && gj < m) ? W[(long)gi * ld + gj] : (gi == gj ? 1.0 : 0.0);
+            tile[r * 33 + c] = (gi < m && gj < m) ? (double)W[(long)gi * ld + gj] : (gi == gj ? 1.0 : 0.0);
         }
         __syncthreads();
         if (t < 64) {
@@ -891,14 +1018,15 @@ __global__ __launch_bounds__(1024) void k_sq_trsv(const double* __restrict__ W, 
 }
 
 // mean[c] = p[c % n] (mp[c] - sum_i R2[i][c] y[i]),  R2 = W2[0:m, c0:c0+D]  (m_new = mp - K z, K z = R2^T R1^-T z)
+template <typename WT>
 __global__ __launch_bounds__(256) void k_sq_mean_update(double* __restrict__ mean, const double* __restrict__ mp,
-                                                        const double* __restrict__ W2, long ld2, int c0,
+                                                        const WT* __restrict__ W2, long ld2, int c0,
                                                         const double* __restrict__ y, int m, int D, SqConst kc) {
     __shared__ double part[4][64];
     const int tx = threadIdx.x & 63, g = threadIdx.x >> 6, c = blockIdx.x * 64 + tx;
     double s = 0.0;
     if (c < D)
-        for (int i = g; i < m; i += 4) s += W2[(long)i * ld2 + c0 + c] * y[i];
+        for (int i = g; i < m; i += 4) s += (double)W2[(long)i * ld2 + c0 + c] * y[i];
     part[g][tx] = s;
     __syncthreads();
     if (g == 0 && c < D) mean[c] = kc.p[c % kc.n] * (mp[c] - (part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]));
@@ -906,7 +1034,8 @@ __global__ __launch_bounds__(256) void k_sq_mean_update(double* __restrict__ mea
 
 // Cl[r][c] = p[r % n] s_c R3[c][r] for c <= r, 0 above: the new factor P R3^T with a non-negative diagonal
 // (R3 = W2[c0 + c][c0 + r]); tile transpose through LDS
-__global__ __launch_bounds__(256) void k_sq_state_out(double* __restrict__ Cl, int D, const double* __restrict__ W2,
+template <typename WT>
+__global__ __launch_bounds__(256) void k_sq_state_out(double* __restrict__ Cl, int D, const WT* __restrict__ W2,
                                                       long ld2, int c0, SqConst kc) {
     __shared__ double tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -915,8 +1044,8 @@ __global__ __launch_bounds__(256) void k_sq_state_out(double* __restrict__ Cl, i
         const int c = cb + q, r = rb + tx;                   // read R3[c][r], contiguous in r
         double v = 0.0;
         if (c < D && r < D && c <= r) {
-            v = W2[(long)(c0 + c) * ld2 + c0 + r];
-            if (W2[(long)(c0 + c) * ld2 + c0 + c] < 0.0) v = -v;
+            v = (double)W2[(long)(c0 + c) * ld2 + c0 + r];
+            if (W2[(long)(c0 + c) * ld2 + c0 + c] < WT(0)) v = -v;
         }
         tile[q][tx] = v;
     }
@@ -944,11 +1073,12 @@ __global__ __launch_bounds__(256) void k_sq_readout(double* __restrict__ means, 
 }
 
 // diag(Sq)[j] = sum_{k <= j} Rq[k][j]^2, Rq = W[0:m, 0:m] upper (white.py:160: sqrt(diag(S)))
-__global__ void k_sq_coldiag(double* __restrict__ out, const double* __restrict__ W, long ld, int m) {
+template <typename WT>
+__global__ void k_sq_coldiag(double* __restrict__ out, const WT* __restrict__ W, long ld, int m) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
     double s = 0.0;
-    for (int k = 0; k <= j; ++k) s += W[(long)k * ld + j] * W[(long)k * ld + j];
+    for (int k = 0; k <= j; ++k) s += (double)W[(long)k * ld + j] * (double)W[(long)k * ld + j];
     out[j] = s;
 }
 
@@ -958,12 +1088,14 @@ struct pnmol_sqrt_filter {
     pnmol_ctx* ctx = nullptr;
     int d = 0, ds = 0, n = 0, nu = 0, nB = 0, m = 0, D = 0;   // ds = state components (d, or 2d: latent-force model), D = n ds
     double A1[SQN * SQN] = {0};
+    int f32 = 0;                // pnmol_filter_desc.dtype = 1: the QR work matrices, the QR itself and Rc in fp32
     double *Hraw = nullptr, *shift = nullptr, *EtT = nullptr, *QlT = nullptr;
+    void *EtT_w = nullptr, *QlT_w = nullptr;   // the same two in the work matrices' element type (fp64: the arrays above)
     double *mean = nullptr, *Cl = nullptr, *T1 = nullptr, *mp = nullptr, *z = nullptr, *y = nullptr, *x = nullptr,
            *norms = nullptr;
     double t = 0.0;
     QrPlan q4;                  // one-QR step: [[T1^T H^T, T1^T], [Rc]] (see sq_step)
-    double* Rc = nullptr;        // R of the step-invariant rows [[Ql^T H^T, Ql^T], [E^T, 0]] for (rc_dt, rc_op)
+    void* Rc = nullptr;          // R of the step-invariant rows [[Ql^T H^T, Ql^T], [E^T, 0]] for (rc_dt, rc_op), element type of q2
     double rc_dt = -1.0, prev_dt = -1.0;
     long opver = 0, rc_op = -1, prev_op = -1;
     QrPlan q1, q2, q3;          // q3: [(H Ql)^T; E^T] of estimate_error (white.py:153-162), factor kept in place
@@ -1013,7 +1145,14 @@ int sq_upload_operator(pnmol_sqrt_filter* f, const double* M, const double* shif
     return 0;
 }
 
-int sq_step(pnmol_sqrt_filter* f, double dt, double* norms_out) {
+// rows x cols block copy between arrays of the work matrices' element type (device to device)
+template <typename WT>
+hipError_t copy_block(WT* dst, long ldd, const void* src, long lds, int rows, int cols, hipStream_t st) {
+    return hipMemcpy2DAsync(dst, sizeof(WT) * ldd, src, sizeof(WT) * lds, sizeof(WT) * cols, rows, hipMemcpyDeviceToDevice, st);
+}
+
+template <typename WT>
+int sq_step_t(pnmol_sqrt_filter* f, double dt, double* norms_out) {
     pnmol_ctx* ctx = f->ctx;
     hipStream_t st = ctx->stream;
     const int d = f->ds, m = f->m, D = f->D;   // d: state components here
@@ -1023,14 +1162,14 @@ int sq_step(pnmol_sqrt_filter* f, double dt, double* norms_out) {
     const int mpad = (m + 31) / 32 * 32;
     const size_t trsv_lds = sizeof(double) * (2 * (size_t)mpad + 32 * 33 + 32 + 128);
     if (trsv_lds > 64 * 1024)   // beyond the default dynamic-LDS limit (m > ~3500: 2-D meshes); create() bounds it by 160 KB
-        QCHECK(ctx, hipFuncSetAttribute((const void*)k_sq_trsv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)trsv_lds));
+        QCHECK(ctx, hipFuncSetAttribute((const void*)k_sq_trsv<WT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)trsv_lds));
     // mp = A Pinv m, T1 = A Pinv Cl, z = H mp + shift (white.py:101-104)
     hipLaunchKernelGGL(k_sq_mean, dim3((d + 255) / 256), dim3(256), 0, st, f->mp, f->mean, d, kc);
     hipLaunchKernelGGL(k_sq_rows, dim3((D + 255) / 256, d), dim3(256), 0, st, f->T1, f->Cl, d, D, kc);
     hipLaunchKernelGGL(k_sq_gemv_z, dim3((m + 3) / 4), dim3(256), 0, st, f->z, f->Hraw, f->mp, f->shift, m, D, kc);
     if (f->err_dt == dt)   // estimate_error: sigma^2 = z^T Sq^-1 z / m = |Rq^-T z|^2 / m (white.py:159)
-        hipLaunchKernelGGL(k_sq_trsv, dim3(1), dim3(1024), trsv_lds, st, f->q3.W, (long)f->q3.ld, m, f->z, f->yq, f->xq,
-                           f->normsq);
+        hipLaunchKernelGGL(k_sq_trsv<WT>, dim3(1), dim3(1024), trsv_lds, st, f->q3.w<WT>(), (long)f->q3.ld, m, f->z, f->yq,
+                           f->xq, f->normsq);
 
     // The reference's two QRs (white.py:114, :120) are one: with [(A Pinv Cl)^T; Ql^T] = Q Rp, the update's pre-array
     // [[Rp H^T, Rp], [E^T, 0]] and  B = [[T1^T H^T, T1^T], [Ql^T H^T, Ql^T], [E^T, 0]]  differ by an orthogonal factor
@@ -1042,53 +1181,75 @@ int sq_step(pnmol_sqrt_filter* f, double dt, double* norms_out) {
     const bool repeat = (f->prev_dt == dt && f->prev_op == f->opver);
     f->prev_dt = dt, f->prev_op = f->opver;
     const bool disabled = std::getenv("PNMOL_SQRT_ONE_QR") && std::atoi(std::getenv("PNMOL_SQRT_ONE_QR")) == 0;
+    WT* Rc = static_cast<WT*>(f->Rc);
     if (repeat && !disabled && !(f->rc_dt == dt && f->rc_op == f->opver)) {
-        QCHECK(ctx, hipMemsetAsync(q2.W, 0, sizeof(double) * (size_t)q2.Mp * q2.ld, st));
-        hipLaunchKernelGGL(k_rht, tiles(m, D), dim3(256), 0, st, q2.W, (long)q2.ld, f->QlT, (long)D, f->Hraw, D, m, kc);
-        QCHECK(ctx, hipMemcpy2DAsync(q2.W + m, sizeof(double) * q2.ld, f->QlT, sizeof(double) * D, sizeof(double) * D, D,
-                                     hipMemcpyDeviceToDevice, st));
-        QCHECK(ctx, hipMemcpy2DAsync(q2.W + (long)D * q2.ld, sizeof(double) * q2.ld, f->EtT, sizeof(double) * m,
-                                     sizeof(double) * m, m, hipMemcpyDeviceToDevice, st));
+        QCHECK(ctx, hipMemsetAsync(q2.W, 0, q2.bytes(), st));
+        hipLaunchKernelGGL((k_rht<WT, double>), tiles(m, D), dim3(256), 0, st, q2.w<WT>(), (long)q2.ld, f->QlT, (long)D,
+                           f->Hraw, D, m, kc);
+        QCHECK(ctx, copy_block<WT>(q2.w<WT>() + m, q2.ld, f->QlT_w, D, D, D, st));
+        QCHECK(ctx, copy_block<WT>(q2.w<WT>() + (long)D * q2.ld, q2.ld, f->EtT_w, m, m, m, st));
         if (int rc = qr_inplace(ctx, q2)) return rc;
-        hipLaunchKernelGGL(k_sq_copy_upper, dim3((q2.ld + 31) / 32, (q2.ld + 7) / 8), dim3(32, 8), 0, st, f->Rc,
-                           (long)q2.ld, q2.W, (long)q2.ld, q2.ld);
+        hipLaunchKernelGGL(k_sq_copy_upper<WT>, dim3((q2.ld + 31) / 32, (q2.ld + 7) / 8), dim3(32, 8), 0, st, Rc,
+                           (long)q2.ld, q2.w<WT>(), (long)q2.ld, q2.ld);
         f->rc_dt = dt, f->rc_op = f->opver;
     }
     const QrPlan* qr = &q2;   // where R = [[R1, R2], [0, R3]] ends up
     if (f->rc_dt == dt && f->rc_op == f->opver && !disabled) {
         const QrPlan& q4 = f->q4;
-        QCHECK(ctx, hipMemsetAsync(q4.W, 0, sizeof(double) * (size_t)q4.Mp * q4.ld, st));
-        hipLaunchKernelGGL(k_sq_tht, tiles(m, D), dim3(256), 0, st, q4.W, (long)q4.ld, f->T1, f->Hraw, D, m, kc,
+        QCHECK(ctx, hipMemsetAsync(q4.W, 0, q4.bytes(), st));
+        hipLaunchKernelGGL(k_sq_tht<WT>, tiles(m, D), dim3(256), 0, st, q4.w<WT>(), (long)q4.ld, f->T1, f->Hraw, D, m, kc,
                            f->cl_tri ? 1 : 0);
-        hipLaunchKernelGGL(k_copy_t, tiles(D, D), dim3(256), 0, st, q4.W + m, (long)q4.ld, f->T1, (long)D, D, D);
-        QCHECK(ctx, hipMemcpy2DAsync(q4.W + (long)Dtop * q4.ld, sizeof(double) * q4.ld, f->Rc, sizeof(double) * q2.ld,
-                                     sizeof(double) * q2.ld, q2.ld, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_copy_t<WT>, tiles(D, D), dim3(256), 0, st, q4.w<WT>() + m, (long)q4.ld, f->T1, (long)D, D, D);
+        QCHECK(ctx, copy_block<WT>(q4.w<WT>() + (long)Dtop * q4.ld, q4.ld, Rc, q2.ld, q2.ld, q2.ld, st));
         if (int rc = qr_inplace(ctx, q4, 0, Dtop / QB)) return rc;
         qr = &q4;
     } else {
         // predict (white.py:114): Cl- = R^T of [(A Pinv Cl)^T; Ql^T]
-        QCHECK(ctx, hipMemsetAsync(q1.W, 0, sizeof(double) * (size_t)q1.Mp * q1.ld, st));
-        hipLaunchKernelGGL(k_copy_t, tiles(D, D), dim3(256), 0, st, q1.W, (long)q1.ld, f->T1, (long)D, D, D);
-        QCHECK(ctx, hipMemcpy2DAsync(q1.W + (long)Dtop * q1.ld, sizeof(double) * q1.ld, f->QlT, sizeof(double) * D,
-                                     sizeof(double) * D, D, hipMemcpyDeviceToDevice, st));
+        QCHECK(ctx, hipMemsetAsync(q1.W, 0, q1.bytes(), st));
+        hipLaunchKernelGGL(k_copy_t<WT>, tiles(D, D), dim3(256), 0, st, q1.w<WT>(), (long)q1.ld, f->T1, (long)D, D, D);
+        QCHECK(ctx, copy_block<WT>(q1.w<WT>() + (long)Dtop * q1.ld, q1.ld, f->QlT_w, D, D, D, st));
         // (A Pinv Cl)^T is upper triangular up to the n x n point blocks when Cl is lower triangular, Ql^T exactly
         if (int rc = qr_inplace(ctx, q1, f->cl_tri ? Dtop / QB : 0)) return rc;
         // update (white.py:120-123): QR of [[R H^T, R], [E^T, 0]]
-        QCHECK(ctx, hipMemsetAsync(q2.W, 0, sizeof(double) * (size_t)q2.Mp * q2.ld, st));
-        hipLaunchKernelGGL(k_rht, tiles(m, D), dim3(256), 0, st, q2.W, (long)q2.ld, q1.W, (long)q1.ld, f->Hraw, D, m, kc);
-        hipLaunchKernelGGL(k_sq_fill_r, dim3((D + 31) / 32, (D + 7) / 8), dim3(32, 8), 0, st, q2.W, (long)q2.ld, m, q1.W,
-                           (long)q1.ld, D);
-        QCHECK(ctx, hipMemcpy2DAsync(q2.W + (long)D * q2.ld, sizeof(double) * q2.ld, f->EtT, sizeof(double) * m,
-                                     sizeof(double) * m, m, hipMemcpyDeviceToDevice, st));
+        QCHECK(ctx, hipMemsetAsync(q2.W, 0, q2.bytes(), st));
+        hipLaunchKernelGGL((k_rht<WT, WT>), tiles(m, D), dim3(256), 0, st, q2.w<WT>(), (long)q2.ld, q1.w<WT>(), (long)q1.ld,
+                           f->Hraw, D, m, kc);
+        hipLaunchKernelGGL(k_sq_fill_r<WT>, dim3((D + 31) / 32, (D + 7) / 8), dim3(32, 8), 0, st, q2.w<WT>(), (long)q2.ld, m,
+                           q1.w<WT>(), (long)q1.ld, D);
+        QCHECK(ctx, copy_block<WT>(q2.w<WT>() + (long)D * q2.ld, q2.ld, f->EtT_w, m, m, m, st));
         if (int rc = qr_inplace(ctx, q2)) return rc;
     }
-    hipLaunchKernelGGL(k_sq_trsv, dim3(1), dim3(1024), trsv_lds, st, qr->W, (long)qr->ld, m, f->z, f->y, f->x, norms_out);
-    hipLaunchKernelGGL(k_sq_mean_update, dim3((D + 63) / 64), dim3(256), 0, st, f->mean, f->mp, qr->W, (long)qr->ld, m,
-                       f->y, m, D, kc);
-    hipLaunchKernelGGL(k_sq_state_out, tiles(D, D), dim3(256), 0, st, f->Cl, D, qr->W, (long)qr->ld, m, kc);
+    hipLaunchKernelGGL(k_sq_trsv<WT>, dim3(1), dim3(1024), trsv_lds, st, qr->w<WT>(), (long)qr->ld, m, f->z, f->y, f->x,
+                       norms_out);
+    hipLaunchKernelGGL(k_sq_mean_update<WT>, dim3((D + 63) / 64), dim3(256), 0, st, f->mean, f->mp, qr->w<WT>(), (long)qr->ld,
+                       m, f->y, m, D, kc);
+    hipLaunchKernelGGL(k_sq_state_out<WT>, tiles(D, D), dim3(256), 0, st, f->Cl, D, qr->w<WT>(), (long)qr->ld, m, kc);
     QCHECK(ctx, hipGetLastError());
     f->t += dt;
     f->cl_tri = true;   // P R3^T
+    return 0;
+}
+
+int sq_step(pnmol_sqrt_filter* f, double dt, double* norms_out) {
+    return f->f32 ? sq_step_t<float>(f, dt, norms_out) : sq_step_t<double>(f, dt, norms_out);
+}
+
+template <typename WT>
+int sq_error_model_t(pnmol_sqrt_filter* f, double dt) {
+    pnmol_ctx* ctx = f->ctx;
+    hipStream_t st = ctx->stream;
+    const int m = f->m, D = f->D;
+    const SqConst kc = sq_const(f, dt);
+    const QrPlan& q3 = f->q3;
+    // Sq = H (Ql Ql^T) H^T + E E^T (white.py:156-158) = R^T R with R of [(H Ql)^T; E^T]; (H Ql)^T = Ql^T H^T, Ql^T upper
+    QCHECK(ctx, hipMemsetAsync(q3.W, 0, q3.bytes(), st));
+    hipLaunchKernelGGL((k_rht<WT, double>), tiles(m, D), dim3(256), 0, st, q3.w<WT>(), (long)q3.ld, f->QlT, (long)D, f->Hraw,
+                       D, m, kc);
+    QCHECK(ctx, copy_block<WT>(q3.w<WT>() + (long)D * q3.ld, q3.ld, f->EtT_w, m, m, m, st));
+    if (int rc = qr_inplace(ctx, q3)) return rc;
+    hipLaunchKernelGGL(k_sq_coldiag<WT>, dim3((m + 255) / 256), dim3(256), 0, st, f->sqdiag, q3.w<WT>(), (long)q3.ld, m);
+    QCHECK(ctx, hipGetLastError());
+    f->err_dt = dt;
     return 0;
 }
 
@@ -1109,8 +1270,13 @@ int pnmol_sqrt_filter_destroy(pnmol_sqrt_filter* f) {
     f->ctx->children.fetch_sub(1);  // (lifetime rule, include/pnmol_hip.h: pnmol_ctx_destroy refuses while filters live)
     hipSetDevice(f->ctx->device);
     for (double* p : {f->Hraw, f->shift, f->EtT, f->QlT, f->mean, f->Cl, f->T1, f->mp, f->z, f->y, f->x, f->norms,
-                      f->sqdiag, f->yq, f->xq, f->normsq, f->Rc})
+                      f->sqdiag, f->yq, f->xq, f->normsq})
         if (p) hipFree(p);
+    if (f->Rc) hipFree(f->Rc);
+    if (f->f32) {   // (fp64: aliases of EtT / QlT)
+        if (f->EtT_w) hipFree(f->EtT_w);
+        if (f->QlT_w) hipFree(f->QlT_w);
+    }
     qr_plan_free(&f->q1);
     qr_plan_free(&f->q2);
     qr_plan_free(&f->q3);
@@ -1132,10 +1298,11 @@ int pnmol_sqrt_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmo
         ctx->err = "pnmol_sqrt_filter_create: d_state must be 0, d (white-noise model) or 2d (latent-force model)";
         return -1;
     }
-    if (desc->dtype != 0) {  // (the square-root form has no fp32 build: refuse rather than silently run fp64)
-        ctx->err = "pnmol_sqrt_filter_create: dtype must be 0 (fp64)";
+    if (desc->dtype != 0 && desc->dtype != 1) {
+        ctx->err = "pnmol_sqrt_filter_create: dtype must be 0 (fp64) or 1 (fp32 QR)";
         return -1;
     }
+    const int f32 = desc->dtype;
     QCHECK(ctx, hipSetDevice(ctx->device));
     if (int rc = qr_configure(ctx)) return rc;
     const int m = d + nB, D = n * ds;
@@ -1145,7 +1312,7 @@ int pnmol_sqrt_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmo
     }
     pnmol_sqrt_filter* f = new pnmol_sqrt_filter();
     ctx->children.fetch_add(1);
-    f->ctx = ctx, f->d = d, f->ds = ds, f->n = n, f->nu = nu, f->nB = nB, f->m = m, f->D = D;
+    f->ctx = ctx, f->d = d, f->ds = ds, f->n = n, f->nu = nu, f->nB = nB, f->m = m, f->D = D, f->f32 = f32;
     if (nB) f->hB.assign(desc->B, desc->B + (size_t)nB * ds);
     double Q1[SQN * SQN] = {0}, Lq[SQN * SQN] = {0};
     for (int a = 0; a < n; ++a)
@@ -1173,11 +1340,11 @@ int pnmol_sqrt_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmo
             !alloc(&f->T1, (size_t)D * D) || !alloc(&f->mp, D) || !alloc(&f->z, m) || !alloc(&f->y, m) ||
             !alloc(&f->x, m) || !alloc(&f->norms, 2) || !alloc(&f->sqdiag, m) || !alloc(&f->yq, m) ||
             !alloc(&f->xq, m) || !alloc(&f->normsq, 2)) { rc = -4; break; }
-        if ((rc = qr_plan_alloc(ctx, (D + QB - 1) / QB * QB + D, D, &f->q1))) { rc = -4; break; }
-        if ((rc = qr_plan_alloc(ctx, D + m, m + D, &f->q2))) { rc = -4; break; }
-        if ((rc = qr_plan_alloc(ctx, D + m, m, &f->q3))) { rc = -4; break; }
-        if ((rc = qr_plan_alloc(ctx, (D + QB - 1) / QB * QB + f->q2.ld, m + D, &f->q4))) { rc = -4; break; }
-        if (!alloc(&f->Rc, (size_t)f->q2.ld * f->q2.ld)) { rc = -4; break; }
+        if ((rc = qr_plan_alloc(ctx, (D + QB - 1) / QB * QB + D, D, &f->q1, f32))) { rc = -4; break; }
+        if ((rc = qr_plan_alloc(ctx, D + m, m + D, &f->q2, f32))) { rc = -4; break; }
+        if ((rc = qr_plan_alloc(ctx, D + m, m, &f->q3, f32))) { rc = -4; break; }
+        if ((rc = qr_plan_alloc(ctx, (D + QB - 1) / QB * QB + f->q2.ld, m + D, &f->q4, f32))) { rc = -4; break; }
+        if (hipMalloc(&f->Rc, f->q2.es() * (size_t)f->q2.ld * f->q2.ld) != hipSuccess) { rc = -4; break; }
         // Ql^T = (Gamma (x) Lq)^T (base/iwp.py:32-53), E^T = blockdiag(E_sqrtm, R_sqrtm)^T (white.py:184)
         std::vector<double> QlT((size_t)D * D, 0.0), EtT((size_t)m * m, 0.0);
         for (int j = 0; j < ds; ++j)
@@ -1194,6 +1361,15 @@ int pnmol_sqrt_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmo
             for (int j = 0; j < nB; ++j) EtT[(size_t)(d + j) * m + d + i] = desc->R_sqrtm[(size_t)i * nB + j];
         if (hipMemcpy(f->QlT, QlT.data(), sizeof(double) * QlT.size(), hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(f->EtT, EtT.data(), sizeof(double) * EtT.size(), hipMemcpyHostToDevice) != hipSuccess) { rc = -2; break; }
+        f->QlT_w = f->QlT, f->EtT_w = f->EtT;
+        if (f32) {   // the two constant blocks as the fp32 work matrices take them
+            f->QlT_w = f->EtT_w = nullptr;
+            std::vector<float> q32(QlT.begin(), QlT.end()), e32(EtT.begin(), EtT.end());
+            if (hipMalloc(&f->QlT_w, sizeof(float) * q32.size()) != hipSuccess ||
+                hipMalloc(&f->EtT_w, sizeof(float) * e32.size()) != hipSuccess) { rc = -4; break; }
+            if (hipMemcpy(f->QlT_w, q32.data(), sizeof(float) * q32.size(), hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(f->EtT_w, e32.data(), sizeof(float) * e32.size(), hipMemcpyHostToDevice) != hipSuccess) { rc = -2; break; }
+        }
         if ((rc = sq_upload_operator(f, desc->L, nullptr))) break;
     } while (0);
     if (rc) {
@@ -1265,22 +1441,8 @@ int pnmol_sqrt_filter_predict_mean(pnmol_sqrt_filter* f, double dt, double* m_at
 
 int pnmol_sqrt_filter_prepare_error_model(pnmol_sqrt_filter* f, double dt) {
     if (!f || !(dt >= 0.0)) return -1;
-    pnmol_ctx* ctx = f->ctx;
-    QCHECK(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
-    const int m = f->m, D = f->D;
-    const SqConst kc = sq_const(f, dt);
-    const QrPlan& q3 = f->q3;
-    // Sq = H (Ql Ql^T) H^T + E E^T (white.py:156-158) = R^T R with R of [(H Ql)^T; E^T]; (H Ql)^T = Ql^T H^T, Ql^T upper
-    QCHECK(ctx, hipMemsetAsync(q3.W, 0, sizeof(double) * (size_t)q3.Mp * q3.ld, st));
-    hipLaunchKernelGGL(k_rht, tiles(m, D), dim3(256), 0, st, q3.W, (long)q3.ld, f->QlT, (long)D, f->Hraw, D, m, kc);
-    QCHECK(ctx, hipMemcpy2DAsync(q3.W + (long)D * q3.ld, sizeof(double) * q3.ld, f->EtT, sizeof(double) * m,
-                                 sizeof(double) * m, m, hipMemcpyDeviceToDevice, st));
-    if (int rc = qr_inplace(ctx, q3)) return rc;
-    hipLaunchKernelGGL(k_sq_coldiag, dim3((m + 255) / 256), dim3(256), 0, st, f->sqdiag, q3.W, (long)q3.ld, m);
-    QCHECK(ctx, hipGetLastError());
-    f->err_dt = dt;
-    return 0;
+    QCHECK(f->ctx, hipSetDevice(f->ctx->device));
+    return f->f32 ? sq_error_model_t<float>(f, dt) : sq_error_model_t<double>(f, dt);
 }
 
 int pnmol_sqrt_filter_step(pnmol_sqrt_filter* f, double dt, pnmol_step_out* info, double* error_estimate_d) {

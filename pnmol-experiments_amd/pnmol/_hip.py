@@ -450,17 +450,20 @@ class State:
 class SqrtFilter:
     """`pnmol_sqrt_filter`: the white-noise EK1 step in square-root (QR) form, one device-resident state."""
 
-    def __init__(self, ctx, *, L, B, E_sqrtm, R_sqrtm, Gamma, num_derivatives):
+    def __init__(self, ctx, *, L, B, E_sqrtm, R_sqrtm, Gamma, num_derivatives, dtype="f64"):
         """L (d, ds), B (nB, ds), Gamma (ds, ds) with ds = d (white-noise) or 2d (latent-force: [L, I], [B, 0],
-        blockdiag(chol K, E_sqrtm), zero noise factors) -- the conventions of `Filter`."""
+        blockdiag(chol K, E_sqrtm), zero noise factors) -- the conventions of `Filter`.  dtype "f32": the QR (work
+        matrices, reflectors, trailing updates) in fp32; the state, the mean path and all scalars stay fp64."""
         self.ctx = ctx
+        self.dtype = dtype
         d, ds = L.shape
         nB = 0 if B is None else B.shape[0]
         self._keep = [_f64(L, (d, ds)), _f64(B if nB else np.zeros((0, ds))), _f64(E_sqrtm, (d, d)),
                       _f64(R_sqrtm if nB else np.zeros((0, 0))), _f64(Gamma, (ds, ds))]
         desc = FilterDesc(d=d, num_derivatives=int(num_derivatives), nB=nB, L=_dp(self._keep[0]),
                           B=_dp(self._keep[1]) if nB else None, E_sqrtm=_dp(self._keep[2]),
-                          R_sqrtm=_dp(self._keep[3]) if nB else None, Gamma=_dp(self._keep[4]), d_state=ds)
+                          R_sqrtm=_dp(self._keep[3]) if nB else None, Gamma=_dp(self._keep[4]), d_state=ds,
+                          dtype=Filter.DTYPES[dtype])
         h = _vp()
         ctx.check(ctx.lib.pnmol_sqrt_filter_create(ctx.handle, ctypes.byref(desc), ctypes.byref(h)),
                   "pnmol_sqrt_filter_create")

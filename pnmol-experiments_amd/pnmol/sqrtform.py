@@ -6,6 +6,11 @@
 when the factor itself is wanted or the covariance form's resolution is not enough; a step costs about 40x the
 covariance form's flops.  `estimate_error` (white.py:153-162) is evaluated in square-root form too, when the step rule
 uses it (Adaptive).  No CPU fallback.
+
+`dtype = "f32"` on a solver of this module runs the QRs in fp32 (work matrices, Householder reflectors and trailing updates on
+`v_mfma_f32_16x16x4_f32`; state, mean path and scalars fp64).  Unlike the fp32 covariance form it holds the north-star
+tolerances at `num_derivatives = 2` and has no std floor (`tools/fp32_sqrt_model.py` predicts it,
+`tests/test_gpu_sqrtform.py` asserts it): a factor loses relative 6e-8 where a covariance loses 6e-8 of its largest entry.
 """
 
 import numpy as np
@@ -33,7 +38,7 @@ class _SqrtFormMixin:
         self._device_pde = pde
         ctx = self._context or _hip.Context.default()
         self._sqrt_filter = _hip.SqrtFilter(ctx, L=pde.L, B=pde.B, E_sqrtm=pde.E_sqrtm, R_sqrtm=pde.R_sqrtm, Gamma=gamma,
-                                            num_derivatives=self.num_derivatives)
+                                            num_derivatives=self.num_derivatives, dtype=self.dtype)
         n, d, nB = self.num_derivatives + 1, pde.L.shape[0], pde.B.shape[0]
         C0_raw = np.kron(gamma, self.diffuse_prior_scale * np.eye(n))
         C0_y0, k_y0, _ = dsqrt.update_sqrt(self.E0, C0_raw, 1e-10 * np.eye(d), ctx=ctx)
@@ -161,7 +166,8 @@ class _SqrtFormLatentMixin(_SqrtFormMixin):
         E = np.asarray(pde.E_sqrtm, dtype=np.float64)
         self._sqrt_filter = _hip.SqrtFilter(
             ctx, L=self._stacked_operator(pde.L), B=np.hstack((pde.B, np.zeros((nB, d)))), E_sqrtm=np.zeros((d, d)),
-            R_sqrtm=np.zeros((nB, nB)), Gamma=scipy.linalg.block_diag(gamma, E), num_derivatives=self.num_derivatives)
+            R_sqrtm=np.zeros((nB, nB)), Gamma=scipy.linalg.block_diag(gamma, E), num_derivatives=self.num_derivatives,
+            dtype=self.dtype)
         c0 = self.diffuse_prior_scale * np.eye(n)
         C_state, k_y0, _ = dsqrt.update_sqrt(self.E0, np.kron(gamma, c0), 1e-6 * np.eye(d), ctx=ctx)
         m_stack = np.concatenate([k_y0 @ pde.y0, np.zeros(D)])

@@ -67,7 +67,7 @@ class _WhiteNoiseEK1Base(pdefilter.PDEFilter):
     def _bind(self, pde, gamma):
         if self.dtype == "f32" and self.num_derivatives > 1 and not self.allow_unstable_f32:
             raise ValueError('dtype="f32" keeps the covariance in single precision, which is only accurate for '
-                             "num_derivatives = 1 (DESIGN.md section 11); use the fp64 path")
+                             'num_derivatives = 1 (DESIGN.md section 11); use the fp64 path, or pnmol.sqrtform with dtype="f32"')
         ctx = self._context or _hip.Context.default()
         gram = self._last_gram if (self._last_gram is not None and self._last_gram.shape == gamma.shape) else gamma @ gamma.T
         self._device_filter = _hip.Filter(ctx, L=pde.L, B=pde.B, E_sqrtm=pde.E_sqrtm, R_sqrtm=pde.R_sqrtm, Gamma=gamma,
