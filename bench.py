@@ -14,7 +14,8 @@ MFMA peak with the ALGORITHMIC flop count F_alg of SURVEY.md section 8d (never t
 At N=1 the line also carries (each driver-timed inside this run):
   batch8_on_1gpu   the 8-problem kappa sweep on this ONE GPU, problems one after the other and all in flight
                    -- the 1-GPU baseline north_star's ">= 6x at 8 GPUs on an 8-problem batch" refers to
-  secondary        ms/step at N=256, N=1024 (fp64) and on the 64x64 2-d mesh (fp64 and fp32 covariance): BASELINE configs 2, 3, 5
+  secondary        ms/step at N=256, N=1024 (fp64) and on the 64x64 2-d mesh (fp64 and fp32 covariance): BASELINE configs 2, 3, 5;
+                   the semilinear step; the square-root (QR) form at the headline size in fp64 and with the fp32 QR
   library_baseline_ms_per_step   the same step written with torch-ROCm library calls (tools/torch_library_step.py)
 """
 
@@ -240,6 +241,26 @@ def secondary_points(device):
         out.append(row)
     except Exception as e:
         out.append({"workload": "spruce budworm semilinear step", "error": repr(e)[:200]})
+    # the step in the reference's own square-root (QR) form on the headline problem (pnmol.sqrtform): fp64, and
+    # the fp32 build of the QR -- the fp32 mode for nu = 2 (section 11).  Steady state: the first two steps of a call
+    # (two QRs each, and the step-invariant rows) are run before the timed ones.
+    for dtype in ("f64", "f32"):
+        name = f"1-D heat N={MESH_N} nu={NU}, square-root (QR) form, {'fp64' if dtype == 'f64' else 'fp32 QR'}"
+        try:
+            import pnmol
+            K = 10
+            pde, _ = build_problem(0.05, K + 3)
+            s = pnmol.sqrtform.LinearWhiteNoiseEK1(num_derivatives=NU, steprule=pnmol.odetools.step.Constant(DT),
+                                                    spatial_kernel=pnmol.kernels.Matern52() + pnmol.kernels.WhiteNoise())
+            s.dtype = dtype
+            st = s.initialize(pde)
+            s._load(st, pde)
+            s._sqrt_filter.steps(3, DT)
+            s._sqrt_filter.steps(K, DT)
+            out.append({"workload": name, "ms_per_step": s._sqrt_filter.last_steps_ms() / K})
+            del s, st
+        except Exception as e:
+            out.append({"workload": name, "error": repr(e)[:200]})
     return out
 
 

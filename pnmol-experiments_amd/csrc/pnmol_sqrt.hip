@@ -131,7 +131,11 @@ __device__ __forceinline__ float copysign_t(float x, float y) { return copysignf
 // parity, published by their owners at the end of the step before): ONE block barrier per column.  Row J of R goes to
 // L.R; the reflector stays unscaled in the registers (scale[J] applied at the end).  Rows beyond the chunk's members are
 // zero on input and stay zero.
-template <typename T>
+// INLOOP (default): V^T V and dlarft's T are formed inside the column loop -- (V^T V)[k][J], k < J, is the inner product every
+// thread of column k forms anyway, and column J-1 of T is a triangular product that the first wave (whose own columns are
+// long finished) does at the top of step J -- and V leaves straight from the registers: no LDS image of V, no Gram product
+// on the MFMA, no serial dlarft behind the loop (8-9 of the 13 us a launch spent outside its column loop).
+template <typename T, bool INLOOP = true>
 __device__ __forceinline__ void qr_factor_body(unsigned char* lds_raw, T* __restrict__ W, long ld, const MemberMap& mm, int p,
                                                int s, int c, T* __restrict__ Vws, T* __restrict__ Tws) {
     FactorLds<T>& L = *reinterpret_cast<FactorLds<T>*>(lds_raw);
@@ -155,9 +159,19 @@ __device__ __forceinline__ void qr_factor_body(unsigned char* lds_raw, T* __rest
     if (g == 0) L.rowb[0][k] = a[0];
     __syncthreads();
 
+    T my_scale = T(0), tau_prev = T(0);
+    T trow[QB];   // threads t < 32: row t of T (dlarft, forward columnwise: T[0:J, J] = -tau_J T[0:J, 0:J] (V^T V)[0:J, J])
 #pragma unroll
     for (int J = 0; J < QB; ++J) {
         const int cur = J & 1;
+        if constexpr (INLOOP) {
+            if (J > 0 && t < QB) {   // column J-1 of T from column J-1 of V^T V (written in step J-1, behind its barrier)
+                T acc = T(0);
+#pragma unroll
+                for (int l = 0; l < J - 1; ++l) acc += trow[l] * L.G[l * QB + (J - 1)];
+                trow[J - 1] = (t < J - 1) ? -tau_prev * acc : (t == J - 1 ? tau_prev : T(0));
+            }
+        }
         T vi[RPT];
         T pk[4] = {0, 0, 0, 0}, pJ[4] = {0, 0, 0, 0};   // four independent accumulation chains each
 #pragma unroll
@@ -192,6 +206,13 @@ __device__ __forceinline__ void qr_factor_body(unsigned char* lds_raw, T* __rest
             scale = copysign_t(rd, alpha);
         }
         const T f = tau * (aJk + sk * scale);  // tau v^T A[:, k]
+        if constexpr (INLOOP) {
+            // k < J: a[] holds reflector k (unscaled) below row k, aJk is its row J, sk its product with rows > J of column J:
+            // v_k^T v_J = scale_k (aJk + scale_J sk)
+            if (k == J) my_scale = scale;
+            if (g == 0 && k < J) L.G[k * QB + J] = my_scale * (aJk + scale * sk);
+            tau_prev = tau;
+        }
         if (g == 0) {
             L.R[J * QB + k] = (k > J) ? aJk - f : (k == J ? beta : T(0));
             if (k == J) {
@@ -217,56 +238,73 @@ __device__ __forceinline__ void qr_factor_body(unsigned char* lds_raw, T* __rest
         __syncthreads();
     }
 
-    // V: unit lower trapezoidal (column k of the reflectors is rows i > k of the registers, unscaled so far)
-    {
-        const T sc = L.scale[k];
+    T* Tg = Tws + (long)c * QB * QB;
+    T* Vg = Vws + (long)c * CR * QB;
+    if constexpr (INLOOP) {
+        if (t < QB) {   // last column of T, then the rows of T
+            T acc = T(0);
+#pragma unroll
+            for (int l = 0; l < QB - 1; ++l) acc += trow[l] * L.G[l * QB + (QB - 1)];
+            trow[QB - 1] = (t < QB - 1) ? -tau_prev * acc : tau_prev;
+#pragma unroll
+            for (int J = 0; J < QB; ++J) Tg[t * QB + J] = trow[J];
+        }
+        // V: unit lower trapezoidal, straight from the registers (column k is rows i > k, scaled now)
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
             const int i = g + NG * r;
-            L.A[i * FLD + k] = (i > k) ? a[r] * sc : (i == k ? T(1) : T(0));
+            Vg[i * QB + k] = (i > k) ? a[r] * my_scale : (i == k ? T(1) : T(0));
         }
-    }
-    __syncthreads();
-    // G = V^T V on the MFMA: waves 0..3 take one 16x16 tile each
-    if (w < 4) {
-        const int fr = lane & 15, fk = lane >> 4, jt = w >> 1, ct = w & 1;
-        typename Mf<T>::acc_t acc = {0, 0, 0, 0};
-        for (int st = 0; st < CR / 4; ++st) {
-            const T va = L.A[(4 * st + fk) * FLD + jt * 16 + fr];
-            const T vb = L.A[(4 * st + fk) * FLD + ct * 16 + fr];
-            acc = Mf<T>::mfma(va, vb, acc);
+    } else {
+        // V: unit lower trapezoidal (column k of the reflectors is rows i > k of the registers, unscaled so far)
+        {
+            const T sc = L.scale[k];
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                const int i = g + NG * r;
+                L.A[i * FLD + k] = (i > k) ? a[r] * sc : (i == k ? T(1) : T(0));
+            }
         }
+        __syncthreads();
+        // G = V^T V on the MFMA: waves 0..3 take one 16x16 tile each
+        if (w < 4) {
+            const int fr = lane & 15, fk = lane >> 4, jt = w >> 1, ct = w & 1;
+            typename Mf<T>::acc_t acc = {0, 0, 0, 0};
+            for (int st = 0; st < CR / 4; ++st) {
+                const T va = L.A[(4 * st + fk) * FLD + jt * 16 + fr];
+                const T vb = L.A[(4 * st + fk) * FLD + ct * 16 + fr];
+                acc = Mf<T>::mfma(va, vb, acc);
+            }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) L.G[(jt * 16 + Mf<T>::row(fk, r)) * QB + ct * 16 + fr] = acc[r];
-    }
-    __syncthreads();
-    // dlarft (forward, columnwise): T[0:J, J] = -tau_J T[0:J, 0:J] (V^T V)[0:J, J]; lane j keeps row j of T
-    T* Tg = Tws + (long)c * QB * QB;
-    if (t < QB) {
-        T trow[QB];
-#pragma unroll
-        for (int J = 0; J < QB; ++J) {
-            T acc = T(0);
-#pragma unroll
-            for (int l = 0; l < J; ++l) acc += trow[l] * L.G[l * QB + J];   // trow[l] = 0 for l < t
-            const T tj = L.tau[J];
-            trow[J] = (t < J) ? -tj * acc : (t == J ? tj : T(0));
+            for (int r = 0; r < 4; ++r) L.G[(jt * 16 + Mf<T>::row(fk, r)) * QB + ct * 16 + fr] = acc[r];
         }
+        __syncthreads();
+        // dlarft (forward, columnwise): T[0:J, J] = -tau_J T[0:J, 0:J] (V^T V)[0:J, J]; lane j keeps row j of T
+        if (t < QB) {
 #pragma unroll
-        for (int J = 0; J < QB; ++J) Tg[t * QB + J] = trow[J];
+            for (int J = 0; J < QB; ++J) {
+                T acc = T(0);
+#pragma unroll
+                for (int l = 0; l < J; ++l) acc += trow[l] * L.G[l * QB + J];   // trow[l] = 0 for l < t
+                const T tj = L.tau[J];
+                trow[J] = (t < J) ? -tj * acc : (t == J ? tj : T(0));
+            }
+#pragma unroll
+            for (int J = 0; J < QB; ++J) Tg[t * QB + J] = trow[J];
+        }
+        // V to the workspace: coalesced from LDS
+        for (int e = t; e < CR * QB; e += FT) Vg[e] = L.A[(e >> 5) * FLD + (e & 31)];
     }
-    // V to the workspace, R (upper, zero below) to the first member: coalesced from LDS
-    T* Vg = Vws + (long)c * CR * QB;
-    for (int e = t; e < CR * QB; e += FT) Vg[e] = L.A[(e >> 5) * FLD + (e & 31)];
+    // R (upper, zero below) to the first member
     for (int e = t; e < QB * QB; e += FT)
         W[((long)member_rb(mm, p, s, c, 0) * QB + (e >> 5)) * ld + (long)p * QB + (e & 31)] = L.R[e];
 }
 
-template <typename T>
+template <typename T, bool INLOOP = true>
 __global__ __launch_bounds__(FT) void k_qr_factor(T* __restrict__ W, long ld, MemberMap mm, int p, int s,
                                                   T* __restrict__ Vws, T* __restrict__ Tws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char qr_lds_raw[];
-    qr_factor_body<T>(qr_lds_raw, W, ld, mm, p, s, blockIdx.x, Vws, Tws);
+    qr_factor_body<T, INLOOP>(qr_lds_raw, W, ld, mm, p, s, blockIdx.x, Vws, Tws);
 }
 
 // C <- (I - V T V^T)^T C = C - V (T^T (V^T C)) on the chunk's rows of 64 trailing columns per block, 16 per wave.  The
@@ -368,14 +406,14 @@ __global__ __launch_bounds__(256) void k_qr_apply(T* __restrict__ W, long ld, Me
 // reflectors of that level, touches the columns behind the panel) and the panel factorisation of the NEXT level `sf` (touches the panel's
 // columns of the level-`sa` survivors, which k_qr_factor of level `sa` left final).  Blocks [0, nchf) factorise -- first in
 // the dispatch order, they are the longer ones --, the rest apply: block nchf + cg * ncha + c is chunk c, column group cg.
-template <typename T>
+template <typename T, bool INLOOP = true>
 __global__ __launch_bounds__(FT) void k_qr_apply_factor(T* __restrict__ W, long ld, MemberMap mm, int p, int sa, int ncha,
                                                         const T* __restrict__ Va, const T* __restrict__ Ta, int col0,
                                                         int ncols, int sf, int nchf, T* __restrict__ Vf, T* __restrict__ Tf) {
     extern __shared__ __attribute__((aligned(16))) unsigned char qr_lds_raw[];
     const int b = blockIdx.x;
     if (b < nchf) {
-        qr_factor_body<T>(qr_lds_raw, W, ld, mm, p, sf, b, Vf, Tf);
+        qr_factor_body<T, INLOOP>(qr_lds_raw, W, ld, mm, p, sf, b, Vf, Tf);
     } else {
         const int a = b - nchf;
         qr_apply_body<T, FT>(qr_lds_raw, W, ld, mm, p, sa, a % ncha, a / ncha, Va, Ta, col0, ncols);
@@ -537,9 +575,11 @@ template <typename T> constexpr size_t kFusedLds = kFactorLds<T> > kApplyLds<T, 
 
 template <typename T>
 int qr_configure_t(pnmol_ctx* ctx) {
-    QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_factor<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFactorLds<T>));
+    QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_factor<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFactorLds<T>));
+    QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_factor<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFactorLds<T>));
     QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_apply<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kApplyLds<T, 256>));
-    QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_apply_factor<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds<T>));
+    QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_apply_factor<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds<T>));
+    QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_apply_factor<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds<T>));
     return 0;
 }
 
@@ -550,7 +590,8 @@ int qr_configure(pnmol_ctx* ctx) {   // attributes are per function and device; 
 
 // The tree levels of one panel: factor(1); [apply(s) + factor(8 s)] in one launch per further level; apply(last level).
 // PNMOL_QR_FUSE=0: factor and apply of a level one after the other (the A/B switch; same arithmetic, same results).
-template <typename T>
+// PNMOL_QR_INLOOP=0: V^T V on the MFMA and dlarft behind the column loop, V through LDS (the earlier form of k_qr_factor).
+template <typename T, bool INLOOP>
 void qr_launch_panel(pnmol_ctx* ctx, const QrPlan& pl, const MemberMap& mm, int p, int ntrail, bool fuse) {
     T* W = pl.w<T>();
     const long ld = pl.ld;
@@ -560,11 +601,11 @@ void qr_launch_panel(pnmol_ctx* ctx, const QrPlan& pl, const MemberMap& mm, int 
     for (int s = 1;; s *= FAN, ++lvl) {
         const int nmem = (mm.cnt + s - 1) / s, nch = (nmem + FAN - 1) / FAN;
         if (lvl == 0 || ntrail <= 0 || !fuse) {
-            hipLaunchKernelGGL(k_qr_factor<T>, dim3(nch), dim3(FT), kFactorLds<T>, ctx->stream, W, ld, mm, p, s, pl.vws<T>(lvl),
-                               pl.tws<T>(lvl));
+            hipLaunchKernelGGL((k_qr_factor<T, INLOOP>), dim3(nch), dim3(FT), kFactorLds<T>, ctx->stream, W, ld, mm, p, s,
+                               pl.vws<T>(lvl), pl.tws<T>(lvl));
         } else {
             const int ncg = (ntrail + FT / 4 - 1) / (FT / 4);
-            hipLaunchKernelGGL(k_qr_apply_factor<T>, dim3(nch + nch_prev * ncg), dim3(FT), kFusedLds<T>, ctx->stream, W, ld, mm,
+            hipLaunchKernelGGL((k_qr_apply_factor<T, INLOOP>), dim3(nch + nch_prev * ncg), dim3(FT), kFusedLds<T>, ctx->stream, W, ld, mm,
                                p, s_prev, nch_prev, pl.vws<T>(lvl - 1), pl.tws<T>(lvl - 1), col0, ntrail, s, nch,
                                pl.vws<T>(lvl), pl.tws<T>(lvl));
         }
@@ -584,6 +625,7 @@ void qr_launch_panel(pnmol_ctx* ctx, const QrPlan& pl, const MemberMap& mm, int 
 // (p >= stacked_tri) the diagonal block is in the triangle, whose blocks p - stacked_tri .. p carry the panel.
 int qr_inplace(pnmol_ctx* ctx, const QrPlan& pl, int tri_bot0 = 0, int stacked_tri = 0) {
     const bool fuse = !(std::getenv("PNMOL_QR_FUSE") && std::atoi(std::getenv("PNMOL_QR_FUSE")) == 0);
+    const bool inloop = !(std::getenv("PNMOL_QR_INLOOP") && std::atoi(std::getenv("PNMOL_QR_INLOOP")) == 0);
     for (int p = 0; p < pl.ncb; ++p) {
         MemberMap mm;
         if (stacked_tri > 0) {
@@ -605,8 +647,13 @@ int qr_inplace(pnmol_ctx* ctx, const QrPlan& pl, int tri_bot0 = 0, int stacked_t
             mm.bot0 = 0;
         }
         const int ntrail = pl.ld - (p + 1) * QB;
-        if (pl.f32) qr_launch_panel<float>(ctx, pl, mm, p, ntrail, fuse);
-        else qr_launch_panel<double>(ctx, pl, mm, p, ntrail, fuse);
+        if (pl.f32) {
+            if (inloop) qr_launch_panel<float, true>(ctx, pl, mm, p, ntrail, fuse);
+            else qr_launch_panel<float, false>(ctx, pl, mm, p, ntrail, fuse);
+        } else {
+            if (inloop) qr_launch_panel<double, true>(ctx, pl, mm, p, ntrail, fuse);
+            else qr_launch_panel<double, false>(ctx, pl, mm, p, ntrail, fuse);
+        }
     }
     QCHECK(ctx, hipGetLastError());
     return 0;
