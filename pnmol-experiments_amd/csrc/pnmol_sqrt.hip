@@ -938,6 +938,55 @@ __global__ __launch_bounds__(256) void k_sq_tht(OT* __restrict__ out, long ldo, 
     }
 }
 
+// The same two products when the rows of H are short (a finite-difference stencil plus the derivative entry: 4-5 entries
+// of D; `ell` built by sq_upload_operator, width <= SQ_ELLW): gathers instead of dense m x D x D products.
+//   k_sq_tht_ell: out[i][j] = sum_e T1[c_e(j)][i] v_e(j) p[c_e(j) % n] -- a 32 x 32 tile per block, T1 rows read along i,
+//                 the tile turned through LDS so that out is written along j
+//   k_rht_ell:    out[i][j] = sum_{e: c_e(j) >= i} R[i][c_e(j)] v_e(j) p[c_e(j) % n] -- one row i of R per block
+constexpr int SQ_ELLW = 8;
+struct SqEll {
+    const int* col;      // [e * m + j], -1: none
+    const double* val;   // [e * m + j]
+    int w;
+};
+
+template <typename OT>
+__global__ __launch_bounds__(256) void k_sq_tht_ell(OT* __restrict__ out, long ldo, const double* __restrict__ T1, SqEll ell,
+                                                    int D, int m, SqConst kc) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32, i = i0 + tx;
+    for (int r = ty; r < 32; r += 8) {
+        const int j = j0 + r;
+        double s = 0.0;
+        if (j < m && i < D)
+            for (int e = 0; e < ell.w; ++e) {
+                const int c = ell.col[e * m + j];
+                if (c >= 0) s += T1[(long)c * D + i] * (ell.val[e * m + j] * kc.p[c % kc.n]);
+            }
+        tile[r][tx] = s;   // tile[j][i]
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int ii = i0 + r, j = j0 + tx;
+        if (ii < D && j < m) out[(long)ii * ldo + j] = (OT)tile[tx][r];
+    }
+}
+
+template <typename OT, typename RT>
+__global__ __launch_bounds__(256) void k_rht_ell(OT* __restrict__ out, long ldo, const RT* __restrict__ R, long ldr, SqEll ell,
+                                                 int D, int m, SqConst kc) {
+    const int i = blockIdx.x;
+    for (int j = threadIdx.x; j < m; j += 256) {
+        double s = 0.0;
+        for (int e = 0; e < ell.w; ++e) {
+            const int c = ell.col[e * m + j];
+            if (c >= i) s += (double)R[(long)i * ldr + c] * (ell.val[e * m + j] * kc.p[c % kc.n]);
+        }
+        out[(long)i * ldo + j] = (OT)s;
+    }
+}
+
 // dst[i][c] = src[i][c] for c >= i, 0 below the diagonal (what a finished QR leaves below R is not R)
 template <typename WT>
 __global__ void k_sq_copy_upper(WT* __restrict__ dst, long ldd, const WT* __restrict__ src, long lds, int n) {
@@ -959,7 +1008,8 @@ __global__ __launch_bounds__(256) void k_sq_gemv_z(double* __restrict__ z, const
 }
 
 // y = R1^-T z and x = R1c^-1 z (R1c = R1 with rows flipped to a positive diagonal; white.py:125 solves with Sl^T = R1),
-// R1 = W[0:m, 0:m] upper.  norms = {|y|^2, |x|^2}.  One block; 32-wide diagonal solves by one wave in registers.
+// R1 = W[0:m, 0:m] upper.  norms = {|y|^2, |x|^2}.  Two blocks -- the two solves do not depend on each other: block 0 the
+// forward one, block 1 the backward one --; 32-wide diagonal solves by one wave in registers.
 template <typename WT>
 __global__ __launch_bounds__(1024) void k_sq_trsv(const WT* __restrict__ W, long ld, int m,
                                                   const double* __restrict__ z, double* __restrict__ y,
@@ -971,96 +1021,90 @@ __global__ __launch_bounds__(1024) void k_sq_trsv(const WT* __restrict__ W, long
     double* tile = ss + mp;                                // 32 x 33
     double* red = tile + 32 * 33;                          // 32
     const int t = threadIdx.x, lane = t & 63;
-    // ---- forward: (R1^T) y = z, right-looking
-    for (int i = t; i < mp; i += 1024) sv[i] = i < m ? z[i] : 0.0;
-    for (int b = 0; b < mb; ++b) {
-        __syncthreads();
-        {
-            const int r = t >> 5, c = t & 31, gi = b * 32 + r, gj = b * 32 + c;
-            tile[r * 33 + c] = (gi < m && gj < m) ? (double)W[(long)gi * ld + gj] : (gi == gj ? 1.0 : 0.0);
-        }
-        __syncthreads();
-        if (t < 64) {
-            const int i = lane & 31;
-            double v = sv[b * 32 + i];
-            for (int k = 0; k < 32; ++k) {
-                const double yk = __shfl(v, k) / tile[k * 33 + k];
-                if (i > k) v -= tile[k * 33 + i] * yk;
-                if (i == k) v = yk;
+    const bool fwd = blockIdx.x == 0;
+    double nrm = 0.0;
+    if (fwd) {
+        // ---- forward: (R1^T) y = z, right-looking
+        for (int i = t; i < mp; i += 1024) sv[i] = i < m ? z[i] : 0.0;
+        for (int b = 0; b < mb; ++b) {
+            __syncthreads();
+            {
+                const int r = t >> 5, c = t & 31, gi = b * 32 + r, gj = b * 32 + c;
+                tile[r * 33 + c] = (gi < m && gj < m) ? (double)W[(long)gi * ld + gj] : (gi == gj ? 1.0 : 0.0);
             }
-            if (lane < 32) ss[b * 32 + i] = v;
-        }
-        __syncthreads();
-        for (int i = (b + 1) * 32 + t; i < m; i += 1024) {
-            double a = 0.0;
+            __syncthreads();
+            if (t < 64) {
+                const int i = lane & 31;
+                double v = sv[b * 32 + i];
+                for (int k = 0; k < 32; ++k) {
+                    const double yk = __shfl(v, k) / tile[k * 33 + k];
+                    if (i > k) v -= tile[k * 33 + i] * yk;
+                    if (i == k) v = yk;
+                }
+                if (lane < 32) ss[b * 32 + i] = v;
+            }
+            __syncthreads();
+            for (int i = (b + 1) * 32 + t; i < m; i += 1024) {
+                double a = 0.0;
 #pragma unroll 8
-            for (int k = 0; k < 32; ++k) {
-                const int gk = b * 32 + k;
-                if (gk < m) a += (double)W[(long)gk * ld + i] * ss[gk];
+                for (int k = 0; k < 32; ++k) {
+                    const int gk = b * 32 + k;
+                    if (gk < m) a += (double)W[(long)gk * ld + i] * ss[gk];
+                }
+                sv[i] -= a;
             }
-            sv[i] -= a;
-        }
-    }
-    __syncthreads();
-    double ny = 0.0;
-    for (int i = t; i < m; i += 1024) {
-        y[i] = ss[i];
-        ny += ss[i] * ss[i];
-    }
-    __syncthreads();
-    // ---- backward: R1 x = S z, left-looking (row dot products)
-    for (int b = mb - 1; b >= 0; --b) {
-        const int r = t >> 5, l32 = t & 31, gi = b * 32 + r;
-        double a = 0.0;
-        if (gi < m)
-            for (int k = (b + 1) * 32 + l32; k < m; k += 32) a += (double)W[(long)gi * ld + k] * ss[k];
-        for (int o = 16; o > 0; o >>= 1) a += __shfl_xor(a, o);
-        if (l32 == 0) {
-            double rhs = 0.0;
-            if (gi < m) rhs = (W[(long)gi * ld + gi] < WT(0) ? -z[gi] : z[gi]) - a;
-            red[r] = rhs;
-        }
-        {
-            const int c = t & 31, gj = b * 32 + c;
-            tile[r * 33 + c] = (gi < m && gj < m) ? (double)W[(long)gi * ld + gj] : (gi == gj ? 1.0 : 0.0);
         }
         __syncthreads();
-        if (t < 64) {
-            const int i = lane & 31;
-            double v = red[i];
-            for (int k = 31; k >= 0; --k) {
-                const double xk = __shfl(v, k) / tile[k * 33 + k];
-                if (i < k) v -= tile[i * 33 + k] * xk;
-                if (i == k) v = xk;
-            }
-            if (lane < 32) ss[b * 32 + i] = v;
+        for (int i = t; i < m; i += 1024) {
+            y[i] = ss[i];
+            nrm += ss[i] * ss[i];
         }
+    } else {
+        // ---- backward: R1 x = S z, left-looking (row dot products)
+        for (int i = t; i < mp; i += 1024) ss[i] = 0.0;
         __syncthreads();
+        for (int b = mb - 1; b >= 0; --b) {
+            const int r = t >> 5, l32 = t & 31, gi = b * 32 + r;
+            double a = 0.0;
+            if (gi < m)
+                for (int k = (b + 1) * 32 + l32; k < m; k += 32) a += (double)W[(long)gi * ld + k] * ss[k];
+            for (int o = 16; o > 0; o >>= 1) a += __shfl_xor(a, o);
+            if (l32 == 0) {
+                double rhs = 0.0;
+                if (gi < m) rhs = (W[(long)gi * ld + gi] < WT(0) ? -z[gi] : z[gi]) - a;
+                red[r] = rhs;
+            }
+            {
+                const int c = t & 31, gj = b * 32 + c;
+                tile[r * 33 + c] = (gi < m && gj < m) ? (double)W[(long)gi * ld + gj] : (gi == gj ? 1.0 : 0.0);
+            }
+            __syncthreads();
+            if (t < 64) {
+                const int i = lane & 31;
+                double v = red[i];
+                for (int k = 31; k >= 0; --k) {
+                    const double xk = __shfl(v, k) / tile[k * 33 + k];
+                    if (i < k) v -= tile[i * 33 + k] * xk;
+                    if (i == k) v = xk;
+                }
+                if (lane < 32) ss[b * 32 + i] = v;
+            }
+            __syncthreads();
+        }
+        for (int i = t; i < m; i += 1024) {
+            x[i] = ss[i];
+            nrm += ss[i] * ss[i];
+        }
     }
-    double nx = 0.0;
-    for (int i = t; i < m; i += 1024) {
-        x[i] = ss[i];
-        nx += ss[i] * ss[i];
-    }
-    // block reduction of the two norms
-    for (int o = 32; o > 0; o >>= 1) {
-        ny += __shfl_xor(ny, o);
-        nx += __shfl_xor(nx, o);
-    }
+    // block reduction of the norm
+    for (int o = 32; o > 0; o >>= 1) nrm += __shfl_xor(nrm, o);
     __syncthreads();
-    if (lane == 0) {
-        tile[t >> 6] = ny;
-        tile[64 + (t >> 6)] = nx;
-    }
+    if (lane == 0) tile[t >> 6] = nrm;
     __syncthreads();
     if (t == 0) {
-        double a = 0.0, c = 0.0;
-        for (int q = 0; q < 16; ++q) {
-            a += tile[q];
-            c += tile[64 + q];
-        }
-        norms[0] = a;
-        norms[1] = c;
+        double a = 0.0;
+        for (int q = 0; q < 16; ++q) a += tile[q];
+        norms[fwd ? 0 : 1] = a;
     }
 }
 
@@ -1138,6 +1182,9 @@ struct pnmol_sqrt_filter {
     int f32 = 0;                // pnmol_filter_desc.dtype = 1: the QR work matrices, the QR itself and Rc in fp32
     double *Hraw = nullptr, *shift = nullptr, *EtT = nullptr, *QlT = nullptr;
     void *EtT_w = nullptr, *QlT_w = nullptr;   // the same two in the work matrices' element type (fp64: the arrays above)
+    int* ell_col = nullptr;     // ELL image of Hraw, [SQ_ELLW * m]; ell_w = 0: some row of H is longer, the dense kernels run
+    double* ell_val = nullptr;
+    int ell_w = 0;
     double *mean = nullptr, *Cl = nullptr, *T1 = nullptr, *mp = nullptr, *z = nullptr, *y = nullptr, *x = nullptr,
            *norms = nullptr;
     double t = 0.0;
@@ -1186,10 +1233,53 @@ int sq_upload_operator(pnmol_sqrt_filter* f, const double* M, const double* shif
         for (int j = 0; j < ds; ++j) H[(size_t)(d + i) * D + (size_t)j * n] = f->hB[(size_t)i * ds + j];
     pnmol_ctx* ctx = f->ctx;
     ++f->opver;
+    {   // short rows (PNMOL_SQRT_ELL=0: always the dense products)
+        std::vector<int> ecol((size_t)SQ_ELLW * m, -1);
+        std::vector<double> eval((size_t)SQ_ELLW * m, 0.0);
+        int w = 0;
+        const bool off = std::getenv("PNMOL_SQRT_ELL") && std::atoi(std::getenv("PNMOL_SQRT_ELL")) == 0;
+        for (int i = 0; i < m && w <= SQ_ELLW && !off; ++i) {
+            int e = 0;
+            for (int k = 0; k < D; ++k) {
+                const double v = H[(size_t)i * D + k];
+                if (v == 0.0) continue;
+                if (e < SQ_ELLW) ecol[(size_t)e * m + i] = k, eval[(size_t)e * m + i] = v;
+                ++e;
+            }
+            w = std::max(w, e);
+        }
+        f->ell_w = (off || w > SQ_ELLW) ? 0 : w;
+        if (f->ell_w) {
+            QCHECK(ctx, hipMemcpyAsync(f->ell_col, ecol.data(), sizeof(int) * ecol.size(), hipMemcpyHostToDevice, ctx->stream));
+            QCHECK(ctx, hipMemcpyAsync(f->ell_val, eval.data(), sizeof(double) * eval.size(), hipMemcpyHostToDevice, ctx->stream));
+            QCHECK(ctx, hipStreamSynchronize(ctx->stream));   // (the two host vectors go out of scope)
+        }
+    }
     QCHECK(ctx, hipMemcpyAsync(f->Hraw, H.data(), sizeof(double) * H.size(), hipMemcpyHostToDevice, ctx->stream));
     QCHECK(ctx, hipMemcpyAsync(f->shift, sh.data(), sizeof(double) * m, hipMemcpyHostToDevice, ctx->stream));
     QCHECK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
+}
+
+// out = (H X^T ...)^T products of the step: the gather kernels when H has an ELL image, the dense MFMA kernels otherwise
+template <typename OT, typename RT>
+void launch_rht(pnmol_sqrt_filter* f, OT* out, long ldo, const RT* R, long ldr, const SqConst& kc) {
+    hipStream_t st = f->ctx->stream;
+    if (f->ell_w)
+        hipLaunchKernelGGL((k_rht_ell<OT, RT>), dim3(f->D), dim3(256), 0, st, out, ldo, R, ldr, SqEll{f->ell_col, f->ell_val, f->ell_w},
+                           f->D, f->m, kc);
+    else
+        hipLaunchKernelGGL((k_rht<OT, RT>), tiles(f->m, f->D), dim3(256), 0, st, out, ldo, R, ldr, f->Hraw, f->D, f->m, kc);
+}
+template <typename OT>
+void launch_tht(pnmol_sqrt_filter* f, OT* out, long ldo, const SqConst& kc) {
+    hipStream_t st = f->ctx->stream;
+    if (f->ell_w)
+        hipLaunchKernelGGL(k_sq_tht_ell<OT>, tiles(f->m, f->D), dim3(256), 0, st, out, ldo, f->T1, SqEll{f->ell_col, f->ell_val, f->ell_w},
+                           f->D, f->m, kc);
+    else
+        hipLaunchKernelGGL(k_sq_tht<OT>, tiles(f->m, f->D), dim3(256), 0, st, out, ldo, f->T1, f->Hraw, f->D, f->m, kc,
+                           f->cl_tri ? 1 : 0);
 }
 
 // rows x cols block copy between arrays of the work matrices' element type (device to device)
@@ -1215,7 +1305,7 @@ int sq_step_t(pnmol_sqrt_filter* f, double dt, double* norms_out) {
     hipLaunchKernelGGL(k_sq_rows, dim3((D + 255) / 256, d), dim3(256), 0, st, f->T1, f->Cl, d, D, kc);
     hipLaunchKernelGGL(k_sq_gemv_z, dim3((m + 3) / 4), dim3(256), 0, st, f->z, f->Hraw, f->mp, f->shift, m, D, kc);
     if (f->err_dt == dt)   // estimate_error: sigma^2 = z^T Sq^-1 z / m = |Rq^-T z|^2 / m (white.py:159)
-        hipLaunchKernelGGL(k_sq_trsv<WT>, dim3(1), dim3(1024), trsv_lds, st, f->q3.w<WT>(), (long)f->q3.ld, m, f->z, f->yq,
+        hipLaunchKernelGGL(k_sq_trsv<WT>, dim3(2), dim3(1024), trsv_lds, st, f->q3.w<WT>(), (long)f->q3.ld, m, f->z, f->yq,
                            f->xq, f->normsq);
 
     // The reference's two QRs (white.py:114, :120) are one: with [(A Pinv Cl)^T; Ql^T] = Q Rp, the update's pre-array
@@ -1231,8 +1321,7 @@ int sq_step_t(pnmol_sqrt_filter* f, double dt, double* norms_out) {
     WT* Rc = static_cast<WT*>(f->Rc);
     if (repeat && !disabled && !(f->rc_dt == dt && f->rc_op == f->opver)) {
         QCHECK(ctx, hipMemsetAsync(q2.W, 0, q2.bytes(), st));
-        hipLaunchKernelGGL((k_rht<WT, double>), tiles(m, D), dim3(256), 0, st, q2.w<WT>(), (long)q2.ld, f->QlT, (long)D,
-                           f->Hraw, D, m, kc);
+        launch_rht<WT, double>(f, q2.w<WT>(), (long)q2.ld, f->QlT, (long)D, kc);
         QCHECK(ctx, copy_block<WT>(q2.w<WT>() + m, q2.ld, f->QlT_w, D, D, D, st));
         QCHECK(ctx, copy_block<WT>(q2.w<WT>() + (long)D * q2.ld, q2.ld, f->EtT_w, m, m, m, st));
         if (int rc = qr_inplace(ctx, q2)) return rc;
@@ -1244,8 +1333,7 @@ int sq_step_t(pnmol_sqrt_filter* f, double dt, double* norms_out) {
     if (f->rc_dt == dt && f->rc_op == f->opver && !disabled) {
         const QrPlan& q4 = f->q4;
         QCHECK(ctx, hipMemsetAsync(q4.W, 0, q4.bytes(), st));
-        hipLaunchKernelGGL(k_sq_tht<WT>, tiles(m, D), dim3(256), 0, st, q4.w<WT>(), (long)q4.ld, f->T1, f->Hraw, D, m, kc,
-                           f->cl_tri ? 1 : 0);
+        launch_tht<WT>(f, q4.w<WT>(), (long)q4.ld, kc);
         hipLaunchKernelGGL(k_copy_t<WT>, tiles(D, D), dim3(256), 0, st, q4.w<WT>() + m, (long)q4.ld, f->T1, (long)D, D, D);
         QCHECK(ctx, copy_block<WT>(q4.w<WT>() + (long)Dtop * q4.ld, q4.ld, Rc, q2.ld, q2.ld, q2.ld, st));
         if (int rc = qr_inplace(ctx, q4, 0, Dtop / QB)) return rc;
@@ -1259,14 +1347,13 @@ int sq_step_t(pnmol_sqrt_filter* f, double dt, double* norms_out) {
         if (int rc = qr_inplace(ctx, q1, f->cl_tri ? Dtop / QB : 0)) return rc;
         // update (white.py:120-123): QR of [[R H^T, R], [E^T, 0]]
         QCHECK(ctx, hipMemsetAsync(q2.W, 0, q2.bytes(), st));
-        hipLaunchKernelGGL((k_rht<WT, WT>), tiles(m, D), dim3(256), 0, st, q2.w<WT>(), (long)q2.ld, q1.w<WT>(), (long)q1.ld,
-                           f->Hraw, D, m, kc);
+        launch_rht<WT, WT>(f, q2.w<WT>(), (long)q2.ld, q1.w<WT>(), (long)q1.ld, kc);
         hipLaunchKernelGGL(k_sq_fill_r<WT>, dim3((D + 31) / 32, (D + 7) / 8), dim3(32, 8), 0, st, q2.w<WT>(), (long)q2.ld, m,
                            q1.w<WT>(), (long)q1.ld, D);
         QCHECK(ctx, copy_block<WT>(q2.w<WT>() + (long)D * q2.ld, q2.ld, f->EtT_w, m, m, m, st));
         if (int rc = qr_inplace(ctx, q2)) return rc;
     }
-    hipLaunchKernelGGL(k_sq_trsv<WT>, dim3(1), dim3(1024), trsv_lds, st, qr->w<WT>(), (long)qr->ld, m, f->z, f->y, f->x,
+    hipLaunchKernelGGL(k_sq_trsv<WT>, dim3(2), dim3(1024), trsv_lds, st, qr->w<WT>(), (long)qr->ld, m, f->z, f->y, f->x,
                        norms_out);
     hipLaunchKernelGGL(k_sq_mean_update<WT>, dim3((D + 63) / 64), dim3(256), 0, st, f->mean, f->mp, qr->w<WT>(), (long)qr->ld,
                        m, f->y, m, D, kc);
@@ -1290,8 +1377,7 @@ int sq_error_model_t(pnmol_sqrt_filter* f, double dt) {
     const QrPlan& q3 = f->q3;
     // Sq = H (Ql Ql^T) H^T + E E^T (white.py:156-158) = R^T R with R of [(H Ql)^T; E^T]; (H Ql)^T = Ql^T H^T, Ql^T upper
     QCHECK(ctx, hipMemsetAsync(q3.W, 0, q3.bytes(), st));
-    hipLaunchKernelGGL((k_rht<WT, double>), tiles(m, D), dim3(256), 0, st, q3.w<WT>(), (long)q3.ld, f->QlT, (long)D, f->Hraw,
-                       D, m, kc);
+    launch_rht<WT, double>(f, q3.w<WT>(), (long)q3.ld, f->QlT, (long)D, kc);
     QCHECK(ctx, copy_block<WT>(q3.w<WT>() + (long)D * q3.ld, q3.ld, f->EtT_w, m, m, m, st));
     if (int rc = qr_inplace(ctx, q3)) return rc;
     hipLaunchKernelGGL(k_sq_coldiag<WT>, dim3((m + 255) / 256), dim3(256), 0, st, f->sqdiag, q3.w<WT>(), (long)q3.ld, m);
@@ -1320,6 +1406,8 @@ int pnmol_sqrt_filter_destroy(pnmol_sqrt_filter* f) {
                       f->sqdiag, f->yq, f->xq, f->normsq})
         if (p) hipFree(p);
     if (f->Rc) hipFree(f->Rc);
+    if (f->ell_col) hipFree(f->ell_col);
+    if (f->ell_val) hipFree(f->ell_val);
     if (f->f32) {   // (fp64: aliases of EtT / QlT)
         if (f->EtT_w) hipFree(f->EtT_w);
         if (f->QlT_w) hipFree(f->QlT_w);
@@ -1386,7 +1474,8 @@ int pnmol_sqrt_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmo
             !alloc(&f->QlT, (size_t)D * D) || !alloc(&f->mean, D) || !alloc(&f->Cl, (size_t)D * D) ||
             !alloc(&f->T1, (size_t)D * D) || !alloc(&f->mp, D) || !alloc(&f->z, m) || !alloc(&f->y, m) ||
             !alloc(&f->x, m) || !alloc(&f->norms, 2) || !alloc(&f->sqdiag, m) || !alloc(&f->yq, m) ||
-            !alloc(&f->xq, m) || !alloc(&f->normsq, 2)) { rc = -4; break; }
+            !alloc(&f->xq, m) || !alloc(&f->normsq, 2) || !alloc(&f->ell_val, (size_t)SQ_ELLW * m) ||
+            hipMalloc(&f->ell_col, sizeof(int) * (size_t)SQ_ELLW * m) != hipSuccess) { rc = -4; break; }
         if ((rc = qr_plan_alloc(ctx, (D + QB - 1) / QB * QB + D, D, &f->q1, f32))) { rc = -4; break; }
         if ((rc = qr_plan_alloc(ctx, D + m, m + D, &f->q2, f32))) { rc = -4; break; }
         if ((rc = qr_plan_alloc(ctx, D + m, m, &f->q3, f32))) { rc = -4; break; }

@@ -245,6 +245,20 @@ def test_one_qr_step_equals_the_two_qr_step(monkeypatch):
     np.testing.assert_allclose(C1, C2, rtol=1e-6, atol=1e-9 * np.abs(C2).max())
 
 
+def test_gather_products_equal_the_dense_products(monkeypatch):
+    """H has short rows (stencil + derivative entry): (H T1)^T and R H^T are gathers over an ELL image of H by default;
+    PNMOL_SQRT_ELL=0 keeps the dense MFMA products.  Same sums up to their order."""
+    N, nu, dt, K = 70, 2, 2.0 ** -7, 5
+    pde, _, _, _ = make_pair(N, nu, dt, K, bcond="neumann")
+    monkeypatch.setenv("PNMOL_SQRT_ELL", "0")
+    t2, m2, s2, sig2, f2 = _sqrt_solver(nu, dt).solve_marginals(pde)
+    monkeypatch.delenv("PNMOL_SQRT_ELL")
+    t1, m1, s1, sig1, f1 = _sqrt_solver(nu, dt).solve_marginals(pde)
+    np.testing.assert_allclose(m1, m2, rtol=1e-9, atol=1e-12 * np.abs(m2).max())
+    np.testing.assert_allclose(s1, s2, rtol=1e-7, atol=1e-12 * s2.max())
+    np.testing.assert_allclose(sig1, sig2, rtol=1e-8)
+
+
 def test_two_dimensional_mesh_square_root_form():
     """2-d Dirichlet heat problem (5-point stencils, nu=1; the shape of BASELINE config 5): 12x12 against the oracle,
     28x28 (D=1568, m=892: three tree levels, a boundary block of 108 rows) against the covariance form on the GPU."""
