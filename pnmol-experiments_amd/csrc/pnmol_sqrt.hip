@@ -131,24 +131,77 @@ __device__ __forceinline__ float copysign_t(float x, float y) { return copysignf
 // parity, published by their owners at the end of the step before): ONE block barrier per column.  Row J of R goes to
 // L.R; the reflector stays unscaled in the registers (scale[J] applied at the end).  Rows beyond the chunk's members are
 // zero on input and stay zero.
+// (defined behind k_qr_factor) the trailing update of one chunk on one 16-column slab per wave, result left in registers
+template <typename T, int NT>
+__device__ __forceinline__ bool qr_apply_core(unsigned char* lds_raw, const T* __restrict__ W, long ld, const MemberMap& mm, int p,
+                                              int s, int c, const T* __restrict__ Vws, const T* __restrict__ Tws, long col,
+                                              T (&cs)[CR / 4], int& nm);
+
 // INLOOP (default): V^T V and dlarft's T are formed inside the column loop -- (V^T V)[k][J], k < J, is the inner product every
 // thread of column k forms anyway, and column J-1 of T is a triangular product that the first wave (whose own columns are
 // long finished) does at the top of step J -- and V leaves straight from the registers: no LDS image of V, no Gram product
 // on the MFMA, no serial dlarft behind the loop (8-9 of the 13 us a launch spent outside its column loop).
-template <typename T, bool INLOOP = true>
+// PRE: the LAST tree level of the panel before (members mma / pa / sa, one chunk, reflectors Va, Ta) has not been applied to
+// this panel's columns yet -- its trailing update runs in this very launch, on the columns behind this panel --: a chunk that
+// holds some of that level's row blocks forms their updated rows itself (two waves, 16 of the 32 columns each) and
+// patches them into its staged copy.  Nothing is written back: below R, a factored panel's columns are never read again.
+template <typename T, bool INLOOP = true, bool PRE = false>
 __device__ __forceinline__ void qr_factor_body(unsigned char* lds_raw, T* __restrict__ W, long ld, const MemberMap& mm, int p,
-                                               int s, int c, T* __restrict__ Vws, T* __restrict__ Tws) {
+                                               int s, int c, T* __restrict__ Vws, T* __restrict__ Tws,
+                                               const MemberMap& mma, int pa, int sa, const T* __restrict__ Va,
+                                               const T* __restrict__ Ta, int* __restrict__ readers) {
     FactorLds<T>& L = *reinterpret_cast<FactorLds<T>*>(lds_raw);
     const int t = threadIdx.x, k = t >> 4, g = t & 15, w = t >> 6, lane = t & 63;
     int nm = 0;
     for (int q = 0; q < FAN; ++q) nm += member_rb(mm, p, s, c, q) >= 0;
-    if (nm == 0 || (nm == 1 && s > 1)) return;  // a lone survivor is already triangular (k_qr_apply skips it too)
+    if (nm == 0 || (nm == 1 && s > 1)) {  // a lone survivor is already triangular (k_qr_apply skips it too)
+        if constexpr (PRE)
+            if (t == 0) __hip_atomic_fetch_add(readers, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
 
+    T pre_cs[CR / 4];
+    int jmap[FAN];
+    bool have_pre = false;
+    if constexpr (PRE) {
+        int any = 0;
+#pragma unroll
+        for (int q = 0; q < FAN; ++q) {
+            const int rbq = member_rb(mma, pa, sa, 0, q);
+            jmap[q] = -1;
+            if (rbq >= 0)
+                for (int j = 0; j < nm; ++j)
+                    if (member_rb(mm, p, s, c, j) == rbq) jmap[q] = j, any = 1;
+        }
+        if (any) {   // (block-uniform)
+            int nma;
+            have_pre = qr_apply_core<T, FT>(lds_raw, W, ld, mma, pa, sa, 0, Va, Ta, (long)p * QB + (w < 2 ? w * 16 : 0) + (lane & 15),
+                                            pre_cs, nma);
+            __syncthreads();   // the LDS image of V, T is dead: the chunk is staged in the same bytes
+        }
+        // This block has read the pending level's rows of this panel's columns (their values went through the products
+        // above): the one row block of that level that is NOT a member of this panel -- the panel before's R row -- may now
+        // be overwritten by the apply block that owns it (qr_apply_body, `writers_wait`).
+        if (t == 0) __hip_atomic_fetch_add(readers, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
     for (int e = t; e < CR * QB; e += FT) {   // coalesced: 32 consecutive columns of one row
         const int i = e >> 5, kk = e & 31, q = i >> 5;
         L.A[i * FLD + kk] = (q < nm) ? W[((long)member_rb(mm, p, s, c, q) * QB + (i & 31)) * ld + (long)p * QB + kk] : T(0);
     }
     __syncthreads();
+    if constexpr (PRE) {
+        if (have_pre) {
+            if (w < 2) {
+                const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll
+                for (int st = 0; st < CR / 4; ++st) {
+                    const int j = jmap[st >> 3], i = 16 * (st >> 2) + Mf<T>::row(fk, st & 3);
+                    if (j >= 0) L.A[(QB * j + (i & 31)) * FLD + w * 16 + fr] = pre_cs[st];
+                }
+            }
+            __syncthreads();
+        }
+    }
     T a[RPT];
 #pragma unroll
     for (int r = 0; r < RPT; ++r) a[r] = L.A[(g + NG * r) * FLD + k];
@@ -304,7 +357,7 @@ template <typename T, bool INLOOP = true>
 __global__ __launch_bounds__(FT) void k_qr_factor(T* __restrict__ W, long ld, MemberMap mm, int p, int s,
                                                   T* __restrict__ Vws, T* __restrict__ Tws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char qr_lds_raw[];
-    qr_factor_body<T, INLOOP>(qr_lds_raw, W, ld, mm, p, s, blockIdx.x, Vws, Tws);
+    qr_factor_body<T, INLOOP, false>(qr_lds_raw, W, ld, mm, p, s, blockIdx.x, Vws, Tws, mm, 0, 0, nullptr, nullptr, nullptr);
 }
 
 // C <- (I - V T V^T)^T C = C - V (T^T (V^T C)) on the chunk's rows of 64 trailing columns per block, 16 per wave.  The
@@ -316,26 +369,21 @@ __global__ __launch_bounds__(FT) void k_qr_factor(T* __restrict__ W, long ld, Me
 // not care which lane group brings which row).
 // NT threads: NT / 64 waves, 16 columns each; cg: the block's column group (NT / 4 columns).
 template <typename T, int NT>
-__device__ __forceinline__ void qr_apply_body(unsigned char* lds_raw, T* __restrict__ W, long ld, const MemberMap& mm, int p,
-                                              int s, int c, int cg, const T* __restrict__ Vws, const T* __restrict__ Tws,
-                                              int col0, int ncols) {
+__device__ __forceinline__ bool qr_apply_core(unsigned char* lds_raw, const T* __restrict__ W, long ld, const MemberMap& mm, int p,
+                                              int s, int c, const T* __restrict__ Vws, const T* __restrict__ Tws, long col,
+                                              T (&cs)[CR / 4], int& nm) {
     constexpr int VLD = Mf<T>::VLD;
     T* sV = reinterpret_cast<T*>(lds_raw);     // CR x VLD
     T* sT = sV + CR * VLD;                      // 32 x VLD
     T* sWall = sT + QB * VLD;                   // per wave: 32 x 17
     const int t = threadIdx.x, w = t >> 6, lane = t & 63, fr = lane & 15, fk = lane >> 4;
-    int nm = 0;
+    nm = 0;
     for (int q = 0; q < FAN; ++q) nm += member_rb(mm, p, s, c, q) >= 0;
-    if (nm == 0 || (nm == 1 && s > 1)) return;
+    if (nm == 0 || (nm == 1 && s > 1)) return false;
     const T* Vg = Vws + (long)c * CR * QB;
     const T* Tg = Tws + (long)c * QB * QB;
     for (int e = t; e < CR * QB; e += NT) sV[(e >> 5) * VLD + (e & 31)] = Vg[e];
     for (int e = t; e < QB * QB; e += NT) sT[(e >> 5) * VLD + (e & 31)] = Tg[e];
-
-    const int cw = cg * (NT / 4) + w * 16;         // this wave's first column, relative to col0
-    const bool active = cw < ncols;                // ncols is a multiple of 16
-    const long col = col0 + (active ? cw : 0) + fr;
-    T cs[CR / 4];
 #pragma unroll
     for (int st = 0; st < CR / 4; ++st) {
         const int i = 16 * (st >> 2) + Mf<T>::row(fk, st & 3), q = i >> 5;
@@ -386,11 +434,38 @@ __device__ __forceinline__ void qr_apply_body(unsigned char* lds_raw, T* __restr
 #pragma unroll
         for (int r = 0; r < 4; ++r) cs[4 * it + r] = acc[r];
     }
-    if (!active) return;
+    return true;
+}
+
+// FIRST (k_qr_apply_factor<.., PRE>): the first 32 columns are the NEXT panel's.  Of those only the level's first row block -- the
+// R row of this panel, not a member of the next one -- is stored (the factor blocks of the same launch bring the other rows'
+// update along in registers, and read all of them from W): after `readers` has reached `readers_target`, i.e. after every
+// factor block of the launch has read them.  The factor blocks come first in the dispatch order and wait for nobody.
+template <typename T, int NT, bool FIRST = false>
+__device__ __forceinline__ void qr_apply_body(unsigned char* lds_raw, T* __restrict__ W, long ld, const MemberMap& mm, int p,
+                                              int s, int c, int cg, const T* __restrict__ Vws, const T* __restrict__ Tws,
+                                              int col0, int ncols, const int* readers = nullptr, int readers_target = 0) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 15, fk = lane >> 4;
+    const int cw = cg * (NT / 4) + w * 16;         // this wave's first column, relative to col0
+    const bool active = cw < ncols;                // ncols is a multiple of 16
+    const long col = col0 + (active ? cw : 0) + fr;
+    T cs[CR / 4];
+    int nm;
+    if (!qr_apply_core<T, NT>(lds_raw, W, ld, mm, p, s, c, Vws, Tws, col, cs, nm) || !active) return;
+    int qend = nm;
+    if constexpr (FIRST) {
+        if (cw < QB) {   // (wave-uniform)
+            qend = 1;
+            for (int spin = 0; spin < (1 << 24); ++spin) {
+                if (__hip_atomic_load(readers, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - readers_target >= 0) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+    }
 #pragma unroll
     for (int st = 0; st < CR / 4; ++st) {
         const int i = 16 * (st >> 2) + Mf<T>::row(fk, st & 3), q = i >> 5;
-        if (q < nm) W[((long)member_rb(mm, p, s, c, q) * QB + (i & 31)) * ld + col] = cs[st];
+        if (q < qend) W[((long)member_rb(mm, p, s, c, q) * QB + (i & 31)) * ld + col] = cs[st];
     }
 }
 
@@ -406,17 +481,20 @@ __global__ __launch_bounds__(256) void k_qr_apply(T* __restrict__ W, long ld, Me
 // reflectors of that level, touches the columns behind the panel) and the panel factorisation of the NEXT level `sf` (touches the panel's
 // columns of the level-`sa` survivors, which k_qr_factor of level `sa` left final).  Blocks [0, nchf) factorise -- first in
 // the dispatch order, they are the longer ones --, the rest apply: block nchf + cg * ncha + c is chunk c, column group cg.
-template <typename T, bool INLOOP = true>
-__global__ __launch_bounds__(FT) void k_qr_apply_factor(T* __restrict__ W, long ld, MemberMap mm, int p, int sa, int ncha,
+// PRE: the apply is the LAST level of panel pa = pf - 1 on the columns behind panel pf, the factorisation the first level of
+// panel pf, whose blocks bring that level's update of their own columns along (qr_factor_body).
+template <typename T, bool INLOOP = true, bool PRE = false>
+__global__ __launch_bounds__(FT) void k_qr_apply_factor(T* __restrict__ W, long ld, MemberMap mma, int pa, int sa, int ncha,
                                                         const T* __restrict__ Va, const T* __restrict__ Ta, int col0,
-                                                        int ncols, int sf, int nchf, T* __restrict__ Vf, T* __restrict__ Tf) {
+                                                        int ncols, MemberMap mmf, int pf, int sf, int nchf,
+                                                        T* __restrict__ Vf, T* __restrict__ Tf, int* readers, int readers_target) {
     extern __shared__ __attribute__((aligned(16))) unsigned char qr_lds_raw[];
     const int b = blockIdx.x;
     if (b < nchf) {
-        qr_factor_body<T, INLOOP>(qr_lds_raw, W, ld, mm, p, sf, b, Vf, Tf);
+        qr_factor_body<T, INLOOP, PRE>(qr_lds_raw, W, ld, mmf, pf, sf, b, Vf, Tf, mma, pa, sa, Va, Ta, readers);
     } else {
         const int a = b - nchf;
-        qr_apply_body<T, FT>(qr_lds_raw, W, ld, mm, p, sa, a % ncha, a / ncha, Va, Ta, col0, ncols);
+        qr_apply_body<T, FT, PRE>(qr_lds_raw, W, ld, mma, pa, sa, a % ncha, a / ncha, Va, Ta, col0, ncols, readers, readers_target);
     }
 }
 
@@ -539,8 +617,12 @@ struct QrPlan {
     int f32 = 0;                                  // element type of W, Vws, Tws: double or float
     int ws_chunks = 0;
     void *W = nullptr, *Vws = nullptr, *Tws = nullptr;
-    template <typename T> T* vws(int lvl) const { return static_cast<T*>(Vws) + (size_t)(lvl & 1) * ws_chunks * CR * QB; }
-    template <typename T> T* tws(int lvl) const { return static_cast<T*>(Tws) + (size_t)(lvl & 1) * ws_chunks * QB * QB; }
+    int* readers = nullptr;            // device counter of k_qr_apply_factor<.., PRE> (factor blocks that have read the pending rows)
+    mutable int readers_target = 0;    // its value once every factor block launched so far has counted (wraps; compared by difference)
+    // four sets of reflector workspaces, by the parities of tree level and panel (what one launch writes, the same launch's
+    // other half -- a level behind, or a panel behind -- reads from another set)
+    template <typename T> T* vws(int lvl, int p) const { return static_cast<T*>(Vws) + (size_t)((lvl & 1) + 2 * (p & 1)) * ws_chunks * CR * QB; }
+    template <typename T> T* tws(int lvl, int p) const { return static_cast<T*>(Tws) + (size_t)((lvl & 1) + 2 * (p & 1)) * ws_chunks * QB * QB; }
     size_t es() const { return f32 ? sizeof(float) : sizeof(double); }
     size_t bytes() const { return es() * (size_t)Mp * ld; }
     template <typename T> T* w() const { return static_cast<T*>(W); }
@@ -556,9 +638,12 @@ int qr_plan_alloc(pnmol_ctx* ctx, int rows, int cols, QrPlan* pl, int f32 = 0) {
     pl->ncb = pl->ld / QB;
     const int maxchunks = (pl->nrb + FAN - 1) / FAN;
     QCHECK(ctx, hipMalloc(&pl->W, pl->bytes()));
-    pl->ws_chunks = maxchunks;   // two sets of reflector workspaces, by tree-level parity (k_qr_apply_factor)
-    QCHECK(ctx, hipMalloc(&pl->Vws, 2 * pl->es() * (size_t)maxchunks * CR * QB));
-    QCHECK(ctx, hipMalloc(&pl->Tws, 2 * pl->es() * (size_t)maxchunks * QB * QB));
+    pl->ws_chunks = maxchunks;
+    QCHECK(ctx, hipMalloc(&pl->Vws, 4 * pl->es() * (size_t)maxchunks * CR * QB));
+    QCHECK(ctx, hipMalloc(&pl->Tws, 4 * pl->es() * (size_t)maxchunks * QB * QB));
+    QCHECK(ctx, hipMalloc(&pl->readers, sizeof(int)));
+    QCHECK(ctx, hipMemset(pl->readers, 0, sizeof(int)));
+    pl->readers_target = 0;
     return 0;
 }
 
@@ -566,6 +651,7 @@ void qr_plan_free(QrPlan* pl) {
     if (pl->W) hipFree(pl->W);
     if (pl->Vws) hipFree(pl->Vws);
     if (pl->Tws) hipFree(pl->Tws);
+    if (pl->readers) hipFree(pl->readers);
     *pl = QrPlan();
 }
 
@@ -578,8 +664,9 @@ int qr_configure_t(pnmol_ctx* ctx) {
     QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_factor<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFactorLds<T>));
     QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_factor<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFactorLds<T>));
     QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_apply<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kApplyLds<T, 256>));
-    QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_apply_factor<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds<T>));
-    QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_apply_factor<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds<T>));
+    QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_apply_factor<T, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds<T>));
+    QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_apply_factor<T, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds<T>));
+    QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_apply_factor<T, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds<T>));
     return 0;
 }
 
@@ -588,30 +675,57 @@ int qr_configure(pnmol_ctx* ctx) {   // attributes are per function and device; 
     return qr_configure_t<float>(ctx);
 }
 
-// The tree levels of one panel: factor(1); [apply(s) + factor(8 s)] in one launch per further level; apply(last level).
-// PNMOL_QR_FUSE=0: factor and apply of a level one after the other (the A/B switch; same arithmetic, same results).
-// PNMOL_QR_INLOOP=0: V^T V on the MFMA and dlarft behind the column loop, V through LDS (the earlier form of k_qr_factor).
+// A trailing update that has not been launched yet: the last tree level of a panel (one chunk), which goes out together with the
+// first factorisation of the next panel (k_qr_apply_factor<.., PRE>).
+struct PendingApply {
+    bool on = false;
+    MemberMap mm{};
+    int p = 0, s = 0, lvl = 0;
+};
+
+// The launches of one panel.  factor(1) -- with the panel before's last trailing update in the same launch when one is
+// pending --; [apply(s) + factor(8 s)] in one launch per further level; the last level's apply stays pending (or, without
+// `pre`, is a launch of its own).  Switches (same arithmetic up to the order of sums, for A/B timings):
+// PNMOL_QR_FUSE=0: factor and apply of a level one after the other.  PNMOL_QR_PRE=1: the last apply of a panel pending as
+// described (default: a launch of its own -- faster, see qr_inplace).  PNMOL_QR_INLOOP=0: V^T V on the MFMA and dlarft behind the column loop, V through LDS (the first k_qr_factor).
 template <typename T, bool INLOOP>
-void qr_launch_panel(pnmol_ctx* ctx, const QrPlan& pl, const MemberMap& mm, int p, int ntrail, bool fuse) {
+void qr_launch_panel(pnmol_ctx* ctx, const QrPlan& pl, const MemberMap& mm, int p, int ntrail, bool fuse, bool pre,
+                     PendingApply& pend) {
     T* W = pl.w<T>();
     const long ld = pl.ld;
     const int col0 = (p + 1) * QB;
     constexpr size_t apply_lds = kApplyLds<T, 256>;
+    constexpr int NCG = FT / 4;   // columns per apply block of the fused launches
     int lvl = 0, s_prev = 0, nch_prev = 0;
     for (int s = 1;; s *= FAN, ++lvl) {
         const int nmem = (mm.cnt + s - 1) / s, nch = (nmem + FAN - 1) / FAN;
-        if (lvl == 0 || ntrail <= 0 || !fuse) {
+        if (lvl == 0 && pend.on) {
+            if constexpr (INLOOP) {
+                // the pending level (one chunk) on this panel's columns (its R row only, see qr_apply_body) and everything behind
+                const int ncols = ntrail + QB, ncg = (ncols + NCG - 1) / NCG;
+                pl.readers_target += nch;
+                hipLaunchKernelGGL((k_qr_apply_factor<T, true, true>), dim3(nch + ncg), dim3(FT), kFusedLds<T>, ctx->stream, W, ld,
+                                   pend.mm, pend.p, pend.s, 1, pl.vws<T>(pend.lvl, pend.p), pl.tws<T>(pend.lvl, pend.p), p * QB, ncols,
+                                   mm, p, s, nch, pl.vws<T>(lvl, p), pl.tws<T>(lvl, p), pl.readers, pl.readers_target);
+            }
+            pend.on = false;
+        } else if (lvl == 0 || ntrail <= 0 || !fuse) {
             hipLaunchKernelGGL((k_qr_factor<T, INLOOP>), dim3(nch), dim3(FT), kFactorLds<T>, ctx->stream, W, ld, mm, p, s,
-                               pl.vws<T>(lvl), pl.tws<T>(lvl));
+                               pl.vws<T>(lvl, p), pl.tws<T>(lvl, p));
         } else {
-            const int ncg = (ntrail + FT / 4 - 1) / (FT / 4);
-            hipLaunchKernelGGL((k_qr_apply_factor<T, INLOOP>), dim3(nch + nch_prev * ncg), dim3(FT), kFusedLds<T>, ctx->stream, W, ld, mm,
-                               p, s_prev, nch_prev, pl.vws<T>(lvl - 1), pl.tws<T>(lvl - 1), col0, ntrail, s, nch,
-                               pl.vws<T>(lvl), pl.tws<T>(lvl));
+            const int ncg = (ntrail + NCG - 1) / NCG;
+            hipLaunchKernelGGL((k_qr_apply_factor<T, INLOOP, false>), dim3(nch + nch_prev * ncg), dim3(FT), kFusedLds<T>,
+                               ctx->stream, W, ld, mm, p, s_prev, nch_prev, pl.vws<T>(lvl - 1, p), pl.tws<T>(lvl - 1, p), col0, ntrail,
+                               mm, p, s, nch, pl.vws<T>(lvl, p), pl.tws<T>(lvl, p), (int*)nullptr, 0);
         }
-        if (ntrail > 0 && (!fuse || nch == 1))
-            hipLaunchKernelGGL(k_qr_apply<T>, dim3(nch, (ntrail + 63) / 64), dim3(256), apply_lds, ctx->stream, W, ld, mm,
-                               p, s, pl.vws<T>(lvl), pl.tws<T>(lvl), col0, ntrail);
+        if (ntrail > 0 && (!fuse || nch == 1)) {
+            if (pre && INLOOP && fuse && nch == 1) {
+                pend.on = true, pend.mm = mm, pend.p = p, pend.s = s, pend.lvl = lvl;
+            } else {
+                hipLaunchKernelGGL(k_qr_apply<T>, dim3(nch, (ntrail + 63) / 64), dim3(256), apply_lds, ctx->stream, W, ld, mm,
+                                   p, s, pl.vws<T>(lvl, p), pl.tws<T>(lvl, p), col0, ntrail);
+            }
+        }
         s_prev = s, nch_prev = nch;
         if (nch == 1) break;
     }
@@ -626,6 +740,10 @@ void qr_launch_panel(pnmol_ctx* ctx, const QrPlan& pl, const MemberMap& mm, int 
 int qr_inplace(pnmol_ctx* ctx, const QrPlan& pl, int tri_bot0 = 0, int stacked_tri = 0) {
     const bool fuse = !(std::getenv("PNMOL_QR_FUSE") && std::atoi(std::getenv("PNMOL_QR_FUSE")) == 0);
     const bool inloop = !(std::getenv("PNMOL_QR_INLOOP") && std::atoi(std::getenv("PNMOL_QR_INLOOP")) == 0);
+    // (measured, N = 512: the pending form is SLOWER -- fp64 7.53 against 7.45 ms per step, fp32 5.74 against 5.36: the update a
+    //  factor block brings along, two waves on 256 x 16 slabs, costs more than the launch it saves -- off unless asked for)
+    const bool pre = std::getenv("PNMOL_QR_PRE") && std::atoi(std::getenv("PNMOL_QR_PRE")) == 1;
+    PendingApply pend;
     for (int p = 0; p < pl.ncb; ++p) {
         MemberMap mm;
         if (stacked_tri > 0) {
@@ -648,11 +766,11 @@ int qr_inplace(pnmol_ctx* ctx, const QrPlan& pl, int tri_bot0 = 0, int stacked_t
         }
         const int ntrail = pl.ld - (p + 1) * QB;
         if (pl.f32) {
-            if (inloop) qr_launch_panel<float, true>(ctx, pl, mm, p, ntrail, fuse);
-            else qr_launch_panel<float, false>(ctx, pl, mm, p, ntrail, fuse);
+            if (inloop) qr_launch_panel<float, true>(ctx, pl, mm, p, ntrail, fuse, pre, pend);
+            else qr_launch_panel<float, false>(ctx, pl, mm, p, ntrail, fuse, pre, pend);
         } else {
-            if (inloop) qr_launch_panel<double, true>(ctx, pl, mm, p, ntrail, fuse);
-            else qr_launch_panel<double, false>(ctx, pl, mm, p, ntrail, fuse);
+            if (inloop) qr_launch_panel<double, true>(ctx, pl, mm, p, ntrail, fuse, pre, pend);
+            else qr_launch_panel<double, false>(ctx, pl, mm, p, ntrail, fuse, pre, pend);
         }
     }
     QCHECK(ctx, hipGetLastError());

@@ -64,10 +64,15 @@ def test_descriptor_dtype_is_validated():
         h = _hip._vp()
         assert lib.pnmol_filter_create(ctx.handle, ctypes.byref(desc), ctypes.byref(h)) == -1
         assert b"dtype" in lib.pnmol_last_error(ctx.handle)
-    desc, keep = _desc(dtype=1)   # fp32 covariance exists for the covariance form only: the QR form must say so
+    for bad in (2, -1, 7):        # the QR form: 0 = fp64, 1 = fp32 QR (include/pnmol_sqrt.h); anything else is refused
+        desc, keep = _desc(dtype=bad)
+        h = _hip._vp()
+        assert lib.pnmol_sqrt_filter_create(ctx.handle, ctypes.byref(desc), ctypes.byref(h)) == -1
+        assert b"dtype" in lib.pnmol_last_error(ctx.handle)
+    desc, keep = _desc(dtype=1)
     h = _hip._vp()
-    assert lib.pnmol_sqrt_filter_create(ctx.handle, ctypes.byref(desc), ctypes.byref(h)) == -1
-    assert b"dtype" in lib.pnmol_last_error(ctx.handle)
+    assert lib.pnmol_sqrt_filter_create(ctx.handle, ctypes.byref(desc), ctypes.byref(h)) == 0
+    assert lib.pnmol_sqrt_filter_destroy(h) == 0
 
 
 def test_python_mirror_frees_states_whatever_the_finalisation_order(hip_ctx):

@@ -245,6 +245,30 @@ def test_one_qr_step_equals_the_two_qr_step(monkeypatch):
     np.testing.assert_allclose(C1, C2, rtol=1e-6, atol=1e-9 * np.abs(C2).max())
 
 
+@pytest.mark.parametrize("env", [{"PNMOL_QR_FUSE": "0"}, {"PNMOL_QR_INLOOP": "0"}, {"PNMOL_QR_PRE": "1"}])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_qr_launch_sequences_agree(monkeypatch, env, dtype):
+    """The launch sequences of the device QR (include/pnmol_sqrt.h; switches documented at qr_launch_panel): the default --
+    trailing update of a tree level and panel factorisation of the next level in one launch, V^T V and T formed inside the column
+    loop -- against each A/B variant, three tree levels (N = 150: 113 row blocks in the first update QR) and two.  Same
+    reflectors up to the order of sums: the solves agree to rounding (fp32 QR: to fp32 rounding)."""
+    N, nu, dt, K = 150, 2, 2.0 ** -7, 4
+    pde, _, _, _ = make_pair(N, nu, dt, K, bcond="neumann")
+
+    def run():
+        s = _sqrt_solver(nu, dt)
+        s.dtype = dtype
+        return s.solve_marginals(pde)
+
+    t1, m1, s1, sig1, f1 = run()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    t2, m2, s2, sig2, f2 = run()
+    tol = 1e-9 if dtype == "f64" else 2e-5
+    np.testing.assert_allclose(m1, m2, rtol=tol, atol=tol * np.abs(m2).max())
+    np.testing.assert_allclose(s1, s2, rtol=100 * tol, atol=tol * s2.max())
+
+
 def test_gather_products_equal_the_dense_products(monkeypatch):
     """H has short rows (stencil + derivative entry): (H T1)^T and R H^T are gathers over an ELL image of H by default;
     PNMOL_SQRT_ELL=0 keeps the dense MFMA products.  Same sums up to their order."""
