@@ -31,7 +31,11 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int QB = 32;            // panel width = row-block height
-constexpr int FAN = 8;            // members per chunk
+#ifndef PNMOL_QR_FAN
+#define PNMOL_QR_FAN 8
+#endif
+constexpr int FAN = PNMOL_QR_FAN; // members per chunk (8, or 4: -DPNMOL_QR_FAN=4 -- half the waves per factor block, one tree level more)
+static_assert(FAN == 8 || FAN == 4, "the factor kernel's row groups are 16 or 8 lanes of a DPP row");
 constexpr int CR = FAN * QB;      // stacked rows of a chunk (256)
 constexpr int FT = FAN * 64;      // threads of k_qr_factor: thread (k, g) = (t & 31, t >> 5), rows g, g + NG, ...
 constexpr int NG = FT / 32;       // row groups (16)
@@ -99,6 +103,17 @@ template <int N>
 __device__ __forceinline__ float row_ror_add(float x) {
     return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x120 + N, 0xf, 0xf, false));
 }
+// x + (x moved by the DPP control word CTRL: 0xB1 / 0x4E = lanes xor 1 / xor 2 within a quad, 0x141 = mirror within 8 lanes)
+template <int CTRL>
+__device__ __forceinline__ double dpp_add(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
+    return x + __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float x) {
+    return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
 
 // 1 / sqrt(x) and 1 / x to the type's precision from the hardware estimates (two Newton steps for fp64, one for fp32)
 __device__ __forceinline__ double rsq_full(double x) {
@@ -151,7 +166,7 @@ __device__ __forceinline__ void qr_factor_body(unsigned char* lds_raw, T* __rest
                                                const MemberMap& mma, int pa, int sa, const T* __restrict__ Va,
                                                const T* __restrict__ Ta, int* __restrict__ readers) {
     FactorLds<T>& L = *reinterpret_cast<FactorLds<T>*>(lds_raw);
-    const int t = threadIdx.x, k = t >> 4, g = t & 15, w = t >> 6, lane = t & 63;
+    const int t = threadIdx.x, k = t / NG, g = t % NG, w = t >> 6, lane = t & 63;
     int nm = 0;
     for (int q = 0; q < FAN; ++q) nm += member_rb(mm, p, s, c, q) >= 0;
     if (nm == 0 || (nm == 1 && s > 1)) {  // a lone survivor is already triangular (k_qr_apply skips it too)
@@ -240,10 +255,16 @@ __device__ __forceinline__ void qr_factor_body(unsigned char* lds_raw, T* __rest
         }
         T sk = (pk[0] + pk[1]) + (pk[2] + pk[3]), sJ = (pJ[0] + pJ[1]) + (pJ[2] + pJ[3]);
         // over the column's 16 row groups = one DPP row of the wave
-        sk = row_ror_add<8>(sk), sJ = row_ror_add<8>(sJ);
-        sk = row_ror_add<4>(sk), sJ = row_ror_add<4>(sJ);
-        sk = row_ror_add<2>(sk), sJ = row_ror_add<2>(sJ);
-        sk = row_ror_add<1>(sk), sJ = row_ror_add<1>(sJ);
+        if constexpr (NG == 16) {
+            sk = row_ror_add<8>(sk), sJ = row_ror_add<8>(sJ);
+            sk = row_ror_add<4>(sk), sJ = row_ror_add<4>(sJ);
+            sk = row_ror_add<2>(sk), sJ = row_ror_add<2>(sJ);
+            sk = row_ror_add<1>(sk), sJ = row_ror_add<1>(sJ);
+        } else {   // 8 lanes: within the quads (xor 1, xor 2), then the two quads of a half row (mirror)
+            sk = dpp_add<0xB1>(sk), sJ = dpp_add<0xB1>(sJ);
+            sk = dpp_add<0x4E>(sk), sJ = dpp_add<0x4E>(sJ);
+            sk = dpp_add<0x141>(sk), sJ = dpp_add<0x141>(sJ);
+        }
         // dlarfg: H = I - tau v v^T, v = [1; x / (alpha - beta)], beta = -sign(alpha) |(alpha, x)|; with
         // nrm = |(alpha, x)|: tau = (beta - alpha) / beta = 1 + |alpha| / nrm, 1 / (alpha - beta) = sign(alpha) / (|alpha| + nrm)
         // -- one rsqrt and one reciprocal on the step's critical path instead of a sqrt and two divisions
@@ -280,7 +301,7 @@ __device__ __forceinline__ void qr_factor_body(unsigned char* lds_raw, T* __rest
                 if (NG * r + NG - 1 > J) a[r] -= fs * vi[r];
         }
         if (J + 1 < QB) {
-            if (w == (J + 1) >> 2) {        // the wave that owns column J+1
+            if (w == ((J + 1) * NG) >> 6) {        // the wave that owns column J+1
                 if (k == J + 1) {
 #pragma unroll
                     for (int r = 0; r < RPT; ++r) L.col[cur ^ 1][g + NG * r] = a[r];
