@@ -23,7 +23,8 @@
  *     left): `pnmol_filter_destroy` while any `pnmol_state` of the filter lives, `pnmol_ctx_destroy` while any
  *     `pnmol_filter` / `pnmol_sqrt_filter` of the ctx lives, `pnmol_state_destroy` of the target of an unfinished
  *     `pnmol_filter_steps_begin`.  The handle stays valid after a refused destroy; call it again once the children are gone.
- *   - `pnmol_abi_version()` = 2 (1: before `pnmol_filter_desc.dtype`, the lifetime rule and `pnmol_filter_sweep_layout`).
+ *   - `pnmol_abi_version()` = 3 (1: before `pnmol_filter_desc.dtype`, the lifetime rule and `pnmol_filter_sweep_layout`;
+ *     2: `pnmol_sqrt_filter_create` refused `dtype = 1`, which now selects the fp32 QR of include/pnmol_sqrt.h).
  *     Zero-initialise `pnmol_filter_desc`: unknown `dtype` values are rejected with -1.
  *   - dtype: fp64 (the reference runs with jax_enable_x64, src/pnmol/__init__.py:9-11); `pnmol_filter_desc.dtype = 1`
  *     keeps the covariance and its bulk kernels in fp32 (build-side option).

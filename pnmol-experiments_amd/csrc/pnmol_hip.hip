@@ -3925,7 +3925,8 @@ int run_error_model_sweep(pnmol_filter* f, const MeasModel& mm) {
 
 extern "C" {
 
-int pnmol_abi_version(void) { return 2; }  // 2: pnmol_filter_desc.dtype, lifetime rule (refused destroys), pnmol_filter_sweep_layout
+// 2: pnmol_filter_desc.dtype, lifetime rule (refused destroys), pnmol_filter_sweep_layout; 3: pnmol_sqrt_filter_create takes dtype = 1
+int pnmol_abi_version(void) { return 3; }
 
 int pnmol_device_count(int* count) {
     if (!count) return -1;

@@ -127,7 +127,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_hip.SYMBOLS), declared ^ set(_hip.SYMBOLS)
     for name in declared:
         assert isinstance(getattr(lib, name), ctypes._CFuncPtr)
-    assert lib.pnmol_abi_version() == 2
+    assert lib.pnmol_abi_version() == 3
     n = ctypes.c_int(-1)
     lib.pnmol_device_count(ctypes.byref(n))
     assert n.value >= 0
