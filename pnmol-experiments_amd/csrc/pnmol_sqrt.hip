@@ -638,10 +638,6 @@ struct QrPlan {
     int f32 = 0;                                  // element type of W, Vws, Tws: double or float
     int ws_chunks = 0;
     void *W = nullptr, *Vws = nullptr, *Tws = nullptr;
-    // the launch sequence of qr_inplace on this plan as an executable graph, per (tri_bot0, stacked_tri): every argument is fixed
-    // by the plan, so one capture serves every later call (a dependent kernel boundary costs 1.6 us in a graph, 2.7 us eager)
-    struct Captured { int key0 = -1, key1 = -1; hipGraphExec_t exec = nullptr; };
-    mutable Captured graphs[3];
     int* readers = nullptr;            // device counter of k_qr_apply_factor<.., PRE> (factor blocks that have read the pending rows)
     mutable int readers_target = 0;    // its value once every factor block launched so far has counted (wraps; compared by difference)
     // four sets of reflector workspaces, by the parities of tree level and panel (what one launch writes, the same launch's
@@ -677,8 +673,6 @@ void qr_plan_free(QrPlan* pl) {
     if (pl->Vws) hipFree(pl->Vws);
     if (pl->Tws) hipFree(pl->Tws);
     if (pl->readers) hipFree(pl->readers);
-    for (auto& g : pl->graphs)
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
     *pl = QrPlan();
 }
 
@@ -801,42 +795,6 @@ int qr_inplace(pnmol_ctx* ctx, const QrPlan& pl, int tri_bot0 = 0, int stacked_t
         }
     }
     QCHECK(ctx, hipGetLastError());
-    return 0;
-}
-
-// qr_inplace replayed from a graph captured on first use (PNMOL_QR_GRAPH=0: launched eagerly every time).  The pending-apply
-// variant counts launches on the host (readers_target) and stays eager.
-int qr_inplace_replay(pnmol_ctx* ctx, const QrPlan& pl, int tri_bot0 = 0, int stacked_tri = 0) {
-    const bool off = (std::getenv("PNMOL_QR_GRAPH") && std::atoi(std::getenv("PNMOL_QR_GRAPH")) == 0) ||
-                     (std::getenv("PNMOL_QR_PRE") && std::atoi(std::getenv("PNMOL_QR_PRE")) == 1);
-    if (off) return qr_inplace(ctx, pl, tri_bot0, stacked_tri);
-    QrPlan::Captured* slot = nullptr;
-    for (auto& g : pl.graphs) {
-        if (g.exec && g.key0 == tri_bot0 && g.key1 == stacked_tri) {
-            QCHECK(ctx, hipGraphLaunch(g.exec, ctx->stream));
-            return 0;
-        }
-        if (!g.exec && !slot) slot = &g;
-    }
-    if (!slot) return qr_inplace(ctx, pl, tri_bot0, stacked_tri);   // (more shapes than slots: not worth caching)
-    hipGraph_t graph = nullptr;
-    QCHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-    const int rc = qr_inplace(ctx, pl, tri_bot0, stacked_tri);
-    const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
-    if (rc != 0 || e != hipSuccess) {
-        if (graph) (void)hipGraphDestroy(graph);
-        if (rc == 0) ctx->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e);
-        return rc != 0 ? rc : -2;
-    }
-    hipGraphExec_t exec = nullptr;
-    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (ei != hipSuccess) {
-        ctx->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(ei);
-        return -2;
-    }
-    slot->key0 = tri_bot0, slot->key1 = stacked_tri, slot->exec = exec;
-    QCHECK(ctx, hipGraphLaunch(exec, ctx->stream));
     return 0;
 }
 
@@ -1505,7 +1463,7 @@ int sq_step_t(pnmol_sqrt_filter* f, double dt, double* norms_out) {
         launch_rht<WT, double>(f, q2.w<WT>(), (long)q2.ld, f->QlT, (long)D, kc);
         QCHECK(ctx, copy_block<WT>(q2.w<WT>() + m, q2.ld, f->QlT_w, D, D, D, st));
         QCHECK(ctx, copy_block<WT>(q2.w<WT>() + (long)D * q2.ld, q2.ld, f->EtT_w, m, m, m, st));
-        if (int rc = qr_inplace_replay(ctx, q2)) return rc;
+        if (int rc = qr_inplace(ctx, q2)) return rc;
         hipLaunchKernelGGL(k_sq_copy_upper<WT>, dim3((q2.ld + 31) / 32, (q2.ld + 7) / 8), dim3(32, 8), 0, st, Rc,
                            (long)q2.ld, q2.w<WT>(), (long)q2.ld, q2.ld);
         f->rc_dt = dt, f->rc_op = f->opver;
@@ -1517,7 +1475,7 @@ int sq_step_t(pnmol_sqrt_filter* f, double dt, double* norms_out) {
         launch_tht<WT>(f, q4.w<WT>(), (long)q4.ld, kc);
         hipLaunchKernelGGL(k_copy_t<WT>, tiles(D, D), dim3(256), 0, st, q4.w<WT>() + m, (long)q4.ld, f->T1, (long)D, D, D);
         QCHECK(ctx, copy_block<WT>(q4.w<WT>() + (long)Dtop * q4.ld, q4.ld, Rc, q2.ld, q2.ld, q2.ld, st));
-        if (int rc = qr_inplace_replay(ctx, q4, 0, Dtop / QB)) return rc;
+        if (int rc = qr_inplace(ctx, q4, 0, Dtop / QB)) return rc;
         qr = &q4;
     } else {
         // predict (white.py:114): Cl- = R^T of [(A Pinv Cl)^T; Ql^T]
@@ -1525,14 +1483,14 @@ int sq_step_t(pnmol_sqrt_filter* f, double dt, double* norms_out) {
         hipLaunchKernelGGL(k_copy_t<WT>, tiles(D, D), dim3(256), 0, st, q1.w<WT>(), (long)q1.ld, f->T1, (long)D, D, D);
         QCHECK(ctx, copy_block<WT>(q1.w<WT>() + (long)Dtop * q1.ld, q1.ld, f->QlT_w, D, D, D, st));
         // (A Pinv Cl)^T is upper triangular up to the n x n point blocks when Cl is lower triangular, Ql^T exactly
-        if (int rc = qr_inplace_replay(ctx, q1, f->cl_tri ? Dtop / QB : 0)) return rc;
+        if (int rc = qr_inplace(ctx, q1, f->cl_tri ? Dtop / QB : 0)) return rc;
         // update (white.py:120-123): QR of [[R H^T, R], [E^T, 0]]
         QCHECK(ctx, hipMemsetAsync(q2.W, 0, q2.bytes(), st));
         launch_rht<WT, WT>(f, q2.w<WT>(), (long)q2.ld, q1.w<WT>(), (long)q1.ld, kc);
         hipLaunchKernelGGL(k_sq_fill_r<WT>, dim3((D + 31) / 32, (D + 7) / 8), dim3(32, 8), 0, st, q2.w<WT>(), (long)q2.ld, m,
                            q1.w<WT>(), (long)q1.ld, D);
         QCHECK(ctx, copy_block<WT>(q2.w<WT>() + (long)D * q2.ld, q2.ld, f->EtT_w, m, m, m, st));
-        if (int rc = qr_inplace_replay(ctx, q2)) return rc;
+        if (int rc = qr_inplace(ctx, q2)) return rc;
     }
     hipLaunchKernelGGL(k_sq_trsv<WT>, dim3(2), dim3(1024), trsv_lds, st, qr->w<WT>(), (long)qr->ld, m, f->z, f->y, f->x,
                        norms_out);
@@ -1560,7 +1518,7 @@ int sq_error_model_t(pnmol_sqrt_filter* f, double dt) {
     QCHECK(ctx, hipMemsetAsync(q3.W, 0, q3.bytes(), st));
     launch_rht<WT, double>(f, q3.w<WT>(), (long)q3.ld, f->QlT, (long)D, kc);
     QCHECK(ctx, copy_block<WT>(q3.w<WT>() + (long)D * q3.ld, q3.ld, f->EtT_w, m, m, m, st));
-    if (int rc = qr_inplace_replay(ctx, q3)) return rc;
+    if (int rc = qr_inplace(ctx, q3)) return rc;
     hipLaunchKernelGGL(k_sq_coldiag<WT>, dim3((m + 255) / 256), dim3(256), 0, st, f->sqdiag, q3.w<WT>(), (long)q3.ld, m);
     QCHECK(ctx, hipGetLastError());
     f->err_dt = dt;
