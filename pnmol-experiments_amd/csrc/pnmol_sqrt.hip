@@ -74,7 +74,7 @@ struct FactorLds {
     T A[CR * FLD];     // the chunk's panel columns (staging of the coalesced load), later V (unit lower trapezoidal)
     T R[QB * QB];      // rows of R as they are finished
     T G[QB * QB];      // V^T V
-    T tau[QB], scale[QB];
+    T tau[QB], scale[QB], beta[QB];
     T col[2][CR];      // column J of the working matrix (ping-pong by step parity)
     T rowb[2][QB];     // row J
 };
@@ -113,6 +113,16 @@ __device__ __forceinline__ double dpp_add(double x) {
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float x) {
     return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+// sum over the NGL (16 or 8) lanes of a column's row groups, left in all of them
+template <int NGL, typename T>
+__device__ __forceinline__ T group_sum(T x) {
+    if constexpr (NGL == 16) {
+        x = row_ror_add<8>(x), x = row_ror_add<4>(x), x = row_ror_add<2>(x), x = row_ror_add<1>(x);
+    } else {   // 8 lanes: within the quads (xor 1, xor 2), then the two quads of a half row (mirror)
+        x = dpp_add<0xB1>(x), x = dpp_add<0x4E>(x), x = dpp_add<0x141>(x);
+    }
+    return x;
 }
 
 // 1 / sqrt(x) and 1 / x to the type's precision from the hardware estimates (two Newton steps for fp64, one for fp32)
@@ -160,11 +170,17 @@ __device__ __forceinline__ bool qr_apply_core(unsigned char* lds_raw, const T* _
 // this panel's columns yet -- its trailing update runs in this very launch, on the columns behind this panel --: a chunk that
 // holds some of that level's row blocks forms their updated rows itself (two waves, 16 of the 32 columns each) and
 // patches them into its staged copy.  Nothing is written back: below R, a factored panel's columns are never read again.
-template <typename T, bool INLOOP = true, bool PRE = false>
+// MODE 2 (default) = INLOOP + the reflector's scalars made ONCE per column: the 16 lanes that own column J+1 form its
+// dlarfg (norm of the rows below the diagonal over their DPP row, tau, scale, beta) right behind their update in step J and
+// leave the three numbers in LDS beside the column; in step J+1 everybody reads them instead of forming them -- 16 FMAs, a
+// DPP reduction and ~25 dependent scalar operations fewer per thread and column (of ~100 instructions; the loop is
+// issue-bound at two waves per SIMD).  MODE 1 = INLOOP as before, MODE 0 = the round-1 form (PNMOL_QR_INLOOP / PNMOL_QR_OWNER).
+template <typename T, int MODE = 2, bool PRE = false>
 __device__ __forceinline__ void qr_factor_body(unsigned char* lds_raw, T* __restrict__ W, long ld, const MemberMap& mm, int p,
                                                int s, int c, T* __restrict__ Vws, T* __restrict__ Tws,
                                                const MemberMap& mma, int pa, int sa, const T* __restrict__ Va,
                                                const T* __restrict__ Ta, int* __restrict__ readers) {
+    constexpr bool INLOOP = MODE >= 1, OWN = MODE == 2;
     FactorLds<T>& L = *reinterpret_cast<FactorLds<T>*>(lds_raw);
     const int t = threadIdx.x, k = t / NG, g = t % NG, w = t >> 6, lane = t & 63;
     int nm = 0;
@@ -225,6 +241,34 @@ __device__ __forceinline__ void qr_factor_body(unsigned char* lds_raw, T* __rest
         for (int r = 0; r < RPT; ++r) L.col[0][g + NG * r] = a[r];
     }
     if (g == 0) L.rowb[0][k] = a[0];
+    // (OWN) dlarfg of column JN by the lanes that hold it (k == JN; the other column groups of the wave compute along and store
+    // nothing): H = I - tau v v^T, v = [1; x / (alpha - beta)], beta = -sign(alpha) |(alpha, x)|; with nrm = |(alpha, x)|:
+    // tau = 1 + |alpha| / nrm, 1 / (alpha - beta) = sign(alpha) / (|alpha| + nrm)
+    auto owner_dlarfg = [&](const int JN) {   // (JN is a constant wherever this is expanded: the column loop is unrolled)
+        T pq[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < RPT; ++r)
+            if (NG * r + NG - 1 > JN) {
+                const T v = (NG * r > JN || g + NG * r > JN) ? a[r] : T(0);
+                pq[r & 3] += v * v;
+            }
+        T sJ = (pq[0] + pq[1]) + (pq[2] + pq[3]);
+        sJ = group_sum<NG>(sJ);
+        const T alpha = a[JN / NG];   // (the lane g == JN % NG holds row JN)
+        T beta = alpha, tau = T(0), scale = T(0);
+        if (sJ != T(0)) {
+            const T n2 = alpha * alpha + sJ, aa = abs_t(alpha);
+            const T rn = rsq_full(n2);
+            const T nrm = n2 * rn, den = aa + nrm;
+            const T rd = rcp_full(den);
+            beta = -copysign_t(nrm, alpha);
+            tau = T(1) + aa * rn;
+            scale = copysign_t(rd, alpha);
+        }
+        if (k == JN && g == JN % NG) L.tau[JN] = tau, L.scale[JN] = scale, L.beta[JN] = beta;
+    };
+    if constexpr (OWN)
+        if (w == 0) owner_dlarfg(0);
     __syncthreads();
 
     T my_scale = T(0), tau_prev = T(0);
@@ -250,12 +294,14 @@ __device__ __forceinline__ void qr_factor_body(unsigned char* lds_raw, T* __rest
                 const T v = L.col[cur][g + NG * r];
                 vi[r] = (NG * r > J || g + NG * r > J) ? v : T(0);
                 pk[r & 3] += vi[r] * a[r];
-                pJ[r & 3] += vi[r] * vi[r];
+                if constexpr (!OWN) pJ[r & 3] += vi[r] * vi[r];
             }
         }
         T sk = (pk[0] + pk[1]) + (pk[2] + pk[3]), sJ = (pJ[0] + pJ[1]) + (pJ[2] + pJ[3]);
         // over the column's 16 row groups = one DPP row of the wave
-        if constexpr (NG == 16) {
+        if constexpr (OWN) {
+            sk = group_sum<NG>(sk);
+        } else if constexpr (NG == 16) {
             sk = row_ror_add<8>(sk), sJ = row_ror_add<8>(sJ);
             sk = row_ror_add<4>(sk), sJ = row_ror_add<4>(sJ);
             sk = row_ror_add<2>(sk), sJ = row_ror_add<2>(sJ);
@@ -270,7 +316,9 @@ __device__ __forceinline__ void qr_factor_body(unsigned char* lds_raw, T* __rest
         // -- one rsqrt and one reciprocal on the step's critical path instead of a sqrt and two divisions
         const T alpha = L.rowb[cur][J], aJk = L.rowb[cur][k];
         T beta = alpha, tau = T(0), scale = T(0);
-        if (sJ != T(0)) {
+        if constexpr (OWN) {
+            tau = L.tau[J], scale = L.scale[J], beta = L.beta[J];
+        } else if (sJ != T(0)) {
             const T n2 = alpha * alpha + sJ, aa = abs_t(alpha);
             const T rn = rsq_full(n2);
             const T nrm = n2 * rn, den = aa + nrm;
@@ -289,7 +337,7 @@ __device__ __forceinline__ void qr_factor_body(unsigned char* lds_raw, T* __rest
         }
         if (g == 0) {
             L.R[J * QB + k] = (k > J) ? aJk - f : (k == J ? beta : T(0));
-            if (k == J) {
+            if (!OWN && k == J) {
                 L.tau[J] = tau;
                 L.scale[J] = scale;
             }
@@ -306,6 +354,7 @@ __device__ __forceinline__ void qr_factor_body(unsigned char* lds_raw, T* __rest
 #pragma unroll
                     for (int r = 0; r < RPT; ++r) L.col[cur ^ 1][g + NG * r] = a[r];
                 }
+                if constexpr (OWN) owner_dlarfg(J + 1);
             }
             if (g == (J + 1) % NG) L.rowb[cur ^ 1][k] = a[(J + 1) / NG];
         }
@@ -374,11 +423,11 @@ __device__ __forceinline__ void qr_factor_body(unsigned char* lds_raw, T* __rest
         W[((long)member_rb(mm, p, s, c, 0) * QB + (e >> 5)) * ld + (long)p * QB + (e & 31)] = L.R[e];
 }
 
-template <typename T, bool INLOOP = true>
+template <typename T, int MODE = 2>
 __global__ __launch_bounds__(FT) void k_qr_factor(T* __restrict__ W, long ld, MemberMap mm, int p, int s,
                                                   T* __restrict__ Vws, T* __restrict__ Tws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char qr_lds_raw[];
-    qr_factor_body<T, INLOOP, false>(qr_lds_raw, W, ld, mm, p, s, blockIdx.x, Vws, Tws, mm, 0, 0, nullptr, nullptr, nullptr);
+    qr_factor_body<T, MODE, false>(qr_lds_raw, W, ld, mm, p, s, blockIdx.x, Vws, Tws, mm, 0, 0, nullptr, nullptr, nullptr);
 }
 
 // C <- (I - V T V^T)^T C = C - V (T^T (V^T C)) on the chunk's rows of 64 trailing columns per block, 16 per wave.  The
@@ -504,7 +553,7 @@ __global__ __launch_bounds__(256) void k_qr_apply(T* __restrict__ W, long ld, Me
 // the dispatch order, they are the longer ones --, the rest apply: block nchf + cg * ncha + c is chunk c, column group cg.
 // PRE: the apply is the LAST level of panel pa = pf - 1 on the columns behind panel pf, the factorisation the first level of
 // panel pf, whose blocks bring that level's update of their own columns along (qr_factor_body).
-template <typename T, bool INLOOP = true, bool PRE = false>
+template <typename T, int MODE = 2, bool PRE = false>
 __global__ __launch_bounds__(FT) void k_qr_apply_factor(T* __restrict__ W, long ld, MemberMap mma, int pa, int sa, int ncha,
                                                         const T* __restrict__ Va, const T* __restrict__ Ta, int col0,
                                                         int ncols, MemberMap mmf, int pf, int sf, int nchf,
@@ -512,7 +561,7 @@ __global__ __launch_bounds__(FT) void k_qr_apply_factor(T* __restrict__ W, long 
     extern __shared__ __attribute__((aligned(16))) unsigned char qr_lds_raw[];
     const int b = blockIdx.x;
     if (b < nchf) {
-        qr_factor_body<T, INLOOP, PRE>(qr_lds_raw, W, ld, mmf, pf, sf, b, Vf, Tf, mma, pa, sa, Va, Ta, readers);
+        qr_factor_body<T, MODE, PRE>(qr_lds_raw, W, ld, mmf, pf, sf, b, Vf, Tf, mma, pa, sa, Va, Ta, readers);
     } else {
         const int a = b - nchf;
         qr_apply_body<T, FT, PRE>(qr_lds_raw, W, ld, mma, pa, sa, a % ncha, a / ncha, Va, Ta, col0, ncols, readers, readers_target);
@@ -682,12 +731,14 @@ template <typename T> constexpr size_t kFusedLds = kFactorLds<T> > kApplyLds<T, 
 
 template <typename T>
 int qr_configure_t(pnmol_ctx* ctx) {
-    QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_factor<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFactorLds<T>));
-    QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_factor<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFactorLds<T>));
+    QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_factor<T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFactorLds<T>));
+    QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_factor<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFactorLds<T>));
+    QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_factor<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFactorLds<T>));
     QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_apply<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kApplyLds<T, 256>));
-    QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_apply_factor<T, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds<T>));
-    QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_apply_factor<T, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds<T>));
-    QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_apply_factor<T, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds<T>));
+    QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_apply_factor<T, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds<T>));
+    QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_apply_factor<T, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds<T>));
+    QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_apply_factor<T, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds<T>));
+    QCHECK(ctx, hipFuncSetAttribute((const void*)k_qr_apply_factor<T, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds<T>));
     return 0;
 }
 
@@ -709,7 +760,7 @@ struct PendingApply {
 // `pre`, is a launch of its own).  Switches (same arithmetic up to the order of sums, for A/B timings):
 // PNMOL_QR_FUSE=0: factor and apply of a level one after the other.  PNMOL_QR_PRE=1: the last apply of a panel pending as
 // described (default: a launch of its own -- faster, see qr_inplace).  PNMOL_QR_INLOOP=0: V^T V on the MFMA and dlarft behind the column loop, V through LDS (the first k_qr_factor).
-template <typename T, bool INLOOP>
+template <typename T, int MODE>
 void qr_launch_panel(pnmol_ctx* ctx, const QrPlan& pl, const MemberMap& mm, int p, int ntrail, bool fuse, bool pre,
                      PendingApply& pend) {
     T* W = pl.w<T>();
@@ -721,26 +772,26 @@ void qr_launch_panel(pnmol_ctx* ctx, const QrPlan& pl, const MemberMap& mm, int 
     for (int s = 1;; s *= FAN, ++lvl) {
         const int nmem = (mm.cnt + s - 1) / s, nch = (nmem + FAN - 1) / FAN;
         if (lvl == 0 && pend.on) {
-            if constexpr (INLOOP) {
+            if constexpr (MODE == 2) {
                 // the pending level (one chunk) on this panel's columns (its R row only, see qr_apply_body) and everything behind
                 const int ncols = ntrail + QB, ncg = (ncols + NCG - 1) / NCG;
                 pl.readers_target += nch;
-                hipLaunchKernelGGL((k_qr_apply_factor<T, true, true>), dim3(nch + ncg), dim3(FT), kFusedLds<T>, ctx->stream, W, ld,
+                hipLaunchKernelGGL((k_qr_apply_factor<T, 2, true>), dim3(nch + ncg), dim3(FT), kFusedLds<T>, ctx->stream, W, ld,
                                    pend.mm, pend.p, pend.s, 1, pl.vws<T>(pend.lvl, pend.p), pl.tws<T>(pend.lvl, pend.p), p * QB, ncols,
                                    mm, p, s, nch, pl.vws<T>(lvl, p), pl.tws<T>(lvl, p), pl.readers, pl.readers_target);
             }
             pend.on = false;
         } else if (lvl == 0 || ntrail <= 0 || !fuse) {
-            hipLaunchKernelGGL((k_qr_factor<T, INLOOP>), dim3(nch), dim3(FT), kFactorLds<T>, ctx->stream, W, ld, mm, p, s,
+            hipLaunchKernelGGL((k_qr_factor<T, MODE>), dim3(nch), dim3(FT), kFactorLds<T>, ctx->stream, W, ld, mm, p, s,
                                pl.vws<T>(lvl, p), pl.tws<T>(lvl, p));
         } else {
             const int ncg = (ntrail + NCG - 1) / NCG;
-            hipLaunchKernelGGL((k_qr_apply_factor<T, INLOOP, false>), dim3(nch + nch_prev * ncg), dim3(FT), kFusedLds<T>,
+            hipLaunchKernelGGL((k_qr_apply_factor<T, MODE, false>), dim3(nch + nch_prev * ncg), dim3(FT), kFusedLds<T>,
                                ctx->stream, W, ld, mm, p, s_prev, nch_prev, pl.vws<T>(lvl - 1, p), pl.tws<T>(lvl - 1, p), col0, ntrail,
                                mm, p, s, nch, pl.vws<T>(lvl, p), pl.tws<T>(lvl, p), (int*)nullptr, 0);
         }
         if (ntrail > 0 && (!fuse || nch == 1)) {
-            if (pre && INLOOP && fuse && nch == 1) {
+            if (pre && MODE == 2 && fuse && nch == 1) {
                 pend.on = true, pend.mm = mm, pend.p = p, pend.s = s, pend.lvl = lvl;
             } else {
                 hipLaunchKernelGGL(k_qr_apply<T>, dim3(nch, (ntrail + 63) / 64), dim3(256), apply_lds, ctx->stream, W, ld, mm,
@@ -761,6 +812,8 @@ void qr_launch_panel(pnmol_ctx* ctx, const QrPlan& pl, const MemberMap& mm, int 
 int qr_inplace(pnmol_ctx* ctx, const QrPlan& pl, int tri_bot0 = 0, int stacked_tri = 0) {
     const bool fuse = !(std::getenv("PNMOL_QR_FUSE") && std::atoi(std::getenv("PNMOL_QR_FUSE")) == 0);
     const bool inloop = !(std::getenv("PNMOL_QR_INLOOP") && std::atoi(std::getenv("PNMOL_QR_INLOOP")) == 0);
+    const bool owner = !(std::getenv("PNMOL_QR_OWNER") && std::atoi(std::getenv("PNMOL_QR_OWNER")) == 0);
+    const int mode = !inloop ? 0 : (owner ? 2 : 1);
     // (measured, N = 512: the pending form is SLOWER -- fp64 7.53 against 7.45 ms per step, fp32 5.74 against 5.36: the update a
     //  factor block brings along, two waves on 256 x 16 slabs, costs more than the launch it saves -- off unless asked for)
     const bool pre = std::getenv("PNMOL_QR_PRE") && std::atoi(std::getenv("PNMOL_QR_PRE")) == 1;
@@ -787,11 +840,13 @@ int qr_inplace(pnmol_ctx* ctx, const QrPlan& pl, int tri_bot0 = 0, int stacked_t
         }
         const int ntrail = pl.ld - (p + 1) * QB;
         if (pl.f32) {
-            if (inloop) qr_launch_panel<float, true>(ctx, pl, mm, p, ntrail, fuse, pre, pend);
-            else qr_launch_panel<float, false>(ctx, pl, mm, p, ntrail, fuse, pre, pend);
+            if (mode == 2) qr_launch_panel<float, 2>(ctx, pl, mm, p, ntrail, fuse, pre, pend);
+            else if (mode == 1) qr_launch_panel<float, 1>(ctx, pl, mm, p, ntrail, fuse, pre, pend);
+            else qr_launch_panel<float, 0>(ctx, pl, mm, p, ntrail, fuse, pre, pend);
         } else {
-            if (inloop) qr_launch_panel<double, true>(ctx, pl, mm, p, ntrail, fuse, pre, pend);
-            else qr_launch_panel<double, false>(ctx, pl, mm, p, ntrail, fuse, pre, pend);
+            if (mode == 2) qr_launch_panel<double, 2>(ctx, pl, mm, p, ntrail, fuse, pre, pend);
+            else if (mode == 1) qr_launch_panel<double, 1>(ctx, pl, mm, p, ntrail, fuse, pre, pend);
+            else qr_launch_panel<double, 0>(ctx, pl, mm, p, ntrail, fuse, pre, pend);
         }
     }
     QCHECK(ctx, hipGetLastError());

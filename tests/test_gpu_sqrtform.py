@@ -245,7 +245,7 @@ def test_one_qr_step_equals_the_two_qr_step(monkeypatch):
     np.testing.assert_allclose(C1, C2, rtol=1e-6, atol=1e-9 * np.abs(C2).max())
 
 
-@pytest.mark.parametrize("env", [{"PNMOL_QR_FUSE": "0"}, {"PNMOL_QR_INLOOP": "0"}, {"PNMOL_QR_PRE": "1"}])
+@pytest.mark.parametrize("env", [{"PNMOL_QR_FUSE": "0"}, {"PNMOL_QR_INLOOP": "0"}, {"PNMOL_QR_OWNER": "0"}, {"PNMOL_QR_PRE": "1"}])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_qr_launch_sequences_agree(monkeypatch, env, dtype):
     """The launch sequences of the device QR (include/pnmol_sqrt.h; switches documented at qr_launch_panel): the default --
