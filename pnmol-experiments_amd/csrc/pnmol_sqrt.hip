@@ -75,7 +75,9 @@ struct FactorLds {
     T R[QB * QB];      // rows of R as they are finished
     T G[QB * QB];      // V^T V
     T tau[QB], scale[QB], beta[QB];
-    T col[2][CR];      // column J of the working matrix (ping-pong by step parity)
+    // column J of the working matrix (ping-pong by step parity), [row group g][r] = row g + NG r with a stride per row group
+    // that keeps the 16-byte accesses of the 16 (or 8) lanes of a column on distinct banks: 20 floats / 18 doubles
+    __attribute__((aligned(16))) T col[2][(CR / RPT) * 20];
     T rowb[2][QB];     // row J
 };
 
@@ -181,6 +183,8 @@ __device__ __forceinline__ void qr_factor_body(unsigned char* lds_raw, T* __rest
                                                const MemberMap& mma, int pa, int sa, const T* __restrict__ Va,
                                                const T* __restrict__ Ta, int* __restrict__ readers) {
     constexpr bool INLOOP = MODE >= 1, OWN = MODE == 2;
+    constexpr int CST = sizeof(T) == 4 ? 20 : 18, VN = 16 / sizeof(T);   // stride of a row group in L.col, elements per 16 bytes
+    typedef T colvec_t __attribute__((ext_vector_type(VN)));
     FactorLds<T>& L = *reinterpret_cast<FactorLds<T>*>(lds_raw);
     const int t = threadIdx.x, k = t / NG, g = t % NG, w = t >> 6, lane = t & 63;
     int nm = 0;
@@ -236,10 +240,17 @@ __device__ __forceinline__ void qr_factor_body(unsigned char* lds_raw, T* __rest
     T a[RPT];
 #pragma unroll
     for (int r = 0; r < RPT; ++r) a[r] = L.A[(g + NG * r) * FLD + k];
-    if (k == 0) {
+    auto col_store = [&](int buf) {   // this thread's RPT rows of its column, as 16-byte stores
+        colvec_t* dst = reinterpret_cast<colvec_t*>(&L.col[buf][g * CST]);
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) L.col[0][g + NG * r] = a[r];
-    }
+        for (int q = 0; q < RPT / VN; ++q) {
+            colvec_t x;
+#pragma unroll
+            for (int e = 0; e < VN; ++e) x[e] = a[q * VN + e];
+            dst[q] = x;
+        }
+    };
+    if (k == 0) col_store(0);
     if (g == 0) L.rowb[0][k] = a[0];
     // (OWN) dlarfg of column JN by the lanes that hold it (k == JN; the other column groups of the wave compute along and store
     // nothing): H = I - tau v v^T, v = [1; x / (alpha - beta)], beta = -sign(alpha) |(alpha, x)|; with nrm = |(alpha, x)|:
@@ -284,14 +295,23 @@ __device__ __forceinline__ void qr_factor_body(unsigned char* lds_raw, T* __rest
                 trow[J - 1] = (t < J - 1) ? -tau_prev * acc : (t == J - 1 ? tau_prev : T(0));
             }
         }
-        T vi[RPT];
+        T vi[RPT], vc[RPT];
+        {   // column J, this thread's rows: 16-byte loads
+            const colvec_t* src = reinterpret_cast<const colvec_t*>(&L.col[cur][g * CST]);
+#pragma unroll
+            for (int q = 0; q < RPT / VN; ++q) {
+                const colvec_t x = src[q];
+#pragma unroll
+                for (int e = 0; e < VN; ++e) vc[q * VN + e] = x[e];
+            }
+        }
         T pk[4] = {0, 0, 0, 0}, pJ[4] = {0, 0, 0, 0};   // four independent accumulation chains each
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {   // rows i = g + 16 r > J of column J (r and J are compile-time after unrolling)
             if (NG * r + NG - 1 <= J) {
                 vi[r] = T(0);
             } else {
-                const T v = L.col[cur][g + NG * r];
+                const T v = vc[r];
                 vi[r] = (NG * r > J || g + NG * r > J) ? v : T(0);
                 pk[r & 3] += vi[r] * a[r];
                 if constexpr (!OWN) pJ[r & 3] += vi[r] * vi[r];
@@ -350,10 +370,7 @@ __device__ __forceinline__ void qr_factor_body(unsigned char* lds_raw, T* __rest
         }
         if (J + 1 < QB) {
             if (w == ((J + 1) * NG) >> 6) {        // the wave that owns column J+1
-                if (k == J + 1) {
-#pragma unroll
-                    for (int r = 0; r < RPT; ++r) L.col[cur ^ 1][g + NG * r] = a[r];
-                }
+                if (k == J + 1) col_store(cur ^ 1);
                 if constexpr (OWN) owner_dlarfg(J + 1);
             }
             if (g == (J + 1) % NG) L.rowb[cur ^ 1][k] = a[(J + 1) / NG];
