@@ -4,12 +4,15 @@
 // What the reference does with `jnp.linalg.qr(mode="r")` (base/sqrt.py:8-95): the R factor of a tall stacked matrix.
 // Here: a communication-avoiding Householder QR (TSQR panels + compact-WY trailing updates on the f64 MFMA).
 //
-//   work matrix W   row-major, Mp x ld doubles, Mp and ld multiples of 32 (zero padded), Mp >= ld
+//   work matrix W   row-major, Mp x ld doubles (floats in the fp32 build), Mp and ld multiples of 32 (zero padded), Mp >= ld
 //   panel p         columns [32p, 32p+32); active row blocks p .. nrb-1 (32 rows each)
 //   tree level s    members = row blocks p + s*k; a chunk = FAN consecutive members (FAN*32 stacked rows).  k_qr_factor
-//                   does a Householder QR of the chunk's 32 panel columns in LDS (LAPACK dlarfg/dlarft conventions), leaves
-//                   R in the chunk's first member and V, T in a workspace; k_qr_apply applies (I - V T V^T)^T to the
-//                   chunk's rows of every trailing column.  Survivors (first members) form level s*FAN, until one is left.
+//                   does a Householder QR of the chunk's 32 panel columns in registers and LDS (LAPACK dlarfg/dlarft
+//                   conventions), leaves R in the chunk's first member and V, T in a workspace; k_qr_apply applies
+//                   (I - V T V^T)^T to the chunk's rows of every trailing column.  Survivors (first members) form level
+//                   s*FAN, until one is left.
+//   launches        per panel: factor(level 1); [apply(level s) + factor(level 8 s)] in ONE launch (k_qr_apply_factor: the two
+//                   do not depend on each other); apply(last level) -- qr_launch_panel.
 //
 // Only R is kept (the reference never forms Q either).  Rows of R are sign-normalised to a non-negative diagonal at the
 // end: the canonical representative of the reference's factor (its signs are LAPACK's, arbitrary).
