@@ -51,7 +51,8 @@ int pnmol_sqrt_update_no_meascov(pnmol_ctx* ctx, const double* H, int m, int D, 
  * `desc->dtype`: 0 = fp64 (the reference's arithmetic, src/pnmol/__init__.py:9-11); 1 = the QRs in fp32 (pre-arrays rounded
  * to fp32, Householder QR and compact-WY updates in fp32 on v_mfma_f32_16x16x4_f32; state, mean path, sigma^2 and all
  * buffers of this interface stay double) -- the fp32 mode for num_derivatives >= 2, where the fp32 covariance form of
- * pnmol_hip.h diverges; other values are refused with -1. */
+ * pnmol_hip.h diverges (mean 1e-5 / std 1e-4 up to 768 mesh points at nu = 2); other values are
+ * refused with -1. */
 typedef struct pnmol_sqrt_filter pnmol_sqrt_filter;
 int pnmol_sqrt_filter_create(pnmol_ctx* ctx, const pnmol_filter_desc* desc, pnmol_sqrt_filter** out);
 int pnmol_sqrt_filter_destroy(pnmol_sqrt_filter* f);

@@ -149,6 +149,14 @@ __device__ __forceinline__ float rcp_full(float x) {
     const float r = __builtin_amdgcn_rcpf(x);
     return r * (2.0f - x * r);
 }
+// dlarfg: a column whose entries below the diagonal have a sum of squares at or below this counts as already eliminated (tau = 0).
+// fp64: exactly zero, as LAPACK.  fp32: squares below ~1e-38 are denormal -- entries of 1e-19.5 .. 1e-22.5, which the noise-free
+// Dirichlet rows produce from N ~ 1000 on (smaller ones square to zero and took the tau = 0 path all along) -- and v_rsq_f32 of a
+// denormal is inf: NaNs from the first step at N = 1024.  Everything below 3e-18 in absolute value is dropped instead; the matrix's
+// own entries are 1e-10 .. 1e3 at 6e-8 relative.
+template <typename T> __device__ __forceinline__ T dlarfg_negligible();
+template <> __device__ __forceinline__ double dlarfg_negligible<double>() { return 0.0; }
+template <> __device__ __forceinline__ float dlarfg_negligible<float>() { return 1e-35f; }
 __device__ __forceinline__ double abs_t(double x) { return fabs(x); }
 __device__ __forceinline__ float abs_t(float x) { return fabsf(x); }
 __device__ __forceinline__ double copysign_t(double x, double y) { return copysign(x, y); }
@@ -270,7 +278,7 @@ __device__ __forceinline__ void qr_factor_body(unsigned char* lds_raw, T* __rest
         sJ = group_sum<NG>(sJ);
         const T alpha = a[JN / NG];   // (the lane g == JN % NG holds row JN)
         T beta = alpha, tau = T(0), scale = T(0);
-        if (sJ != T(0)) {
+        if (!(sJ <= dlarfg_negligible<T>())) {
             const T n2 = alpha * alpha + sJ, aa = abs_t(alpha);
             const T rn = rsq_full(n2);
             const T nrm = n2 * rn, den = aa + nrm;
@@ -341,7 +349,7 @@ __device__ __forceinline__ void qr_factor_body(unsigned char* lds_raw, T* __rest
         T beta = alpha, tau = T(0), scale = T(0);
         if constexpr (OWN) {
             tau = L.tau[J], scale = L.scale[J], beta = L.beta[J];
-        } else if (sJ != T(0)) {
+        } else if (!(sJ <= dlarfg_negligible<T>())) {
             const T n2 = alpha * alpha + sJ, aa = abs_t(alpha);
             const T rn = rsq_full(n2);
             const T nrm = n2 * rn, den = aa + nrm;

@@ -10,7 +10,9 @@ uses it (Adaptive).  No CPU fallback.
 `dtype = "f32"` on a solver of this module runs the QRs in fp32 (work matrices, Householder reflectors and trailing updates on
 `v_mfma_f32_16x16x4_f32`; state, mean path and scalars fp64).  Unlike the fp32 covariance form it holds the north-star
 tolerances at `num_derivatives = 2` and has no std floor (`tools/fp32_sqrt_model.py` predicts it,
-`tests/test_gpu_sqrtform.py` asserts it): a factor loses relative 6e-8 where a covariance loses 6e-8 of its largest entry.
+`tests/test_gpu_sqrt_fp32.py` asserts it): a factor loses relative 6e-8 where a covariance loses 6e-8 of its largest entry.
+Its std error grows with the mesh (7e-5 relative at N = 512 .. 768): the mode is specified up to 768 mesh points in 1-d with
+`num_derivatives = 2`; at N = 1024 it is finite and the mean holds 1e-5, but the stds are at 2.6e-4.
 """
 
 import numpy as np

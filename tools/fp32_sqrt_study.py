@@ -4,7 +4,7 @@ errors of the posterior mean / marginal std relative to the LARGEST mean / std (
 entries >= 1 % of the largest std ("significant").
   * 1-d heat, nu = 2, N = 64 / 128 / 256 (40 / 40 / 100 steps): fp32 QR and fp64 QR on the GPU against the CPU oracle
     (N = 256: the committed 100-step fixture of BASELINE config 2) -- the workload on which the fp32 COVARIANCE form diverges;
-  * 1-d heat, nu = 2, N = 512, 30 steps: fp32 QR against the fp64 QR form on the GPU, ms per step of both;
+  * 1-d heat, nu = 2, N = 512 (30 steps) and N = 1024 (24 steps): fp32 QR against the fp64 QR form on the GPU, ms per step of both;
   * 2-d heat, nu = 1, 12x12 and 28x28: against the CPU oracle (the fp32 covariance form's floor there: 1.3e-3 / 4.1e-3).
 Prints one JSON line per case (log: profiles/r03_sqrt_fp32/fp32_sqrt_study.log)."""
 import json, pathlib, sys
@@ -56,15 +56,16 @@ for N, K in ((64, 40), (128, 40), (256, 100)):
         row.update(err_rows(dtype, m, sd, om, os_))
     print(json.dumps(row), flush=True)
 
-N, K = 512, 30
-out = {}
-for dtype in ("f64", "f32"):
-    s = sqrt_solver(2, DT, dtype)
-    t, m, sd, sig, _ = s.solve_marginals(heat1d(pnmol.pde.examples, N, K))
-    out[dtype] = (m, sd, s._sqrt_filter.last_steps_ms() / K)
-row = {"case": f"1-d N={N} nu=2, {K} steps, fp32 QR vs fp64 QR on the GPU", "ms_per_step_f64": out["f64"][2], "ms_per_step_f32": out["f32"][2]}
-row.update(err_rows("f32", out["f32"][0], out["f32"][1], out["f64"][0], out["f64"][1]))
-print(json.dumps(row), flush=True)
+for N, K in ((512, 30), (1024, 24)):
+    out = {}
+    for dtype in ("f64", "f32"):
+        s = sqrt_solver(2, DT, dtype)
+        t, m, sd, sig, _ = s.solve_marginals(heat1d(pnmol.pde.examples, N, K))
+        out[dtype] = (m, sd, s._sqrt_filter.last_steps_ms() / K)
+        del s
+    row = {"case": f"1-d N={N} nu=2, {K} steps, fp32 QR vs fp64 QR on the GPU", "ms_per_step_f64": out["f64"][2], "ms_per_step_f32": out["f32"][2]}
+    row.update(err_rows("f32", out["f32"][0], out["f32"][1], out["f64"][0], out["f64"][1]))
+    print(json.dumps(row), flush=True)
 
 for n, K in ((12, 12), (28, 8)):
     dt = 2.0 ** -8
