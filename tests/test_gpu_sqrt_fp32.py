@@ -136,6 +136,25 @@ def test_fp32_qr_adaptive_steps_follow_the_oracle(semilinear):
     np.testing.assert_allclose(sol.mean[:, 0], osol.mean[:, 0], rtol=1e-5, atol=1e-5 * np.abs(osol.mean[:, 0]).max())
 
 
+@pytest.mark.parametrize("N,bcond", [(24, "neumann"), (24, "dirichlet"), (96, "neumann")])
+def test_fp32_qr_latent_force_model(N, bcond):
+    """The latent-force EK1 (latent.py:155-233; state [u; eps], noise-free update, nuggets 1e-6: conditioned ~1e10) with the QRs
+    in fp32 against the fp64 QR form on the device, both halves of the state (tools/diag_latent_f32.py: mean <= 6e-7, std <= 1e-5)."""
+    nu, dt, K = 2, 2.0 ** -6, 6
+    kw = dict(tmax=K * dt, dx=1.0 / (N - 1), diffusion_rate=0.05, bcond=bcond, kernel=pnmol.kernels.SquareExponential())
+    pde = pnmol.pde.examples.heat_1d_discretized(**kw)
+    k = pnmol.kernels.SquareExponential() + pnmol.kernels.WhiteNoise()
+    out = {}
+    for dtype in ("f64", "f32"):
+        s = pnmol.sqrtform.LinearLatentForceEK1(num_derivatives=nu, steprule=pnmol.odetools.step.Constant(dt), spatial_kernel=k)
+        s.dtype = dtype
+        out[dtype] = s.solve(pde)
+    a, b = out["f32"], out["f64"]
+    np.testing.assert_allclose(a.mean, b.mean, rtol=1e-5, atol=1e-5 * np.abs(b.mean).max())
+    va, vb = np.einsum("tij,tij->ti", a.cov_sqrtm, a.cov_sqrtm), np.einsum("tij,tij->ti", b.cov_sqrtm, b.cov_sqrtm)
+    np.testing.assert_allclose(np.sqrt(va), np.sqrt(vb), rtol=1e-4, atol=1e-4 * np.sqrt(vb).max())
+
+
 def test_fp32_qr_two_dimensional_mesh():
     """2-d Dirichlet heat problem, nu = 1 (the shape of BASELINE config 5), 12 x 12 against the oracle: the fp32 QR form has
     no std floor there either (the fp32 covariance form: 1.3e-3 of max(std), tests/test_gpu_fp32.py)."""
